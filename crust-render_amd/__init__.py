@@ -1,0 +1,485 @@
+"""crust-render_amd — MI355X-native backend for crust-render's kernel seam.
+
+Host-side mirror (Python; the reference's own toolchain, Rust, is absent from this image) of the
+reference's operator interface over the C ABI in include/crt.h:
+
+    crust_rt::Geometry / SceneBuilder / Scene / Ray / RayHit   crates/crust-rt/src/scene.rs:87-479
+    crust_core::WorldBuilder / World                            crates/crust-core/src/rt_world.rs:89-294
+    crust_core::Renderer / RenderSettings                       crates/crust-core/src/tracer.rs:137-735
+
+Everything that computes runs in libcrt_amd.so (hand-written HIP for gfx950). There is no CPU fallback:
+if the library is missing, or no HIP device is usable, the calls raise.
+
+The directory name contains a hyphen, so the package is imported through `load()` in
+__graft_entry__.py / tests/conftest.py under the module name `crust_render_amd`.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcrt_amd.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+MASK_CAMERA, MASK_SHADOW, MASK_INDIRECT, MASK_ALL = 1, 2, 4, 0xFFFFFFFF
+INVALID_ID = 0xFFFFFFFF
+INF = float("inf")
+
+CRT_OK = 0
+_ERRORS = {-1: "CRT_ERR_BAD_ARG", -2: "CRT_ERR_BAD_ID", -3: "CRT_ERR_NO_DEVICE", -4: "CRT_ERR_STACK",
+           -5: "CRT_ERR_UNSUPPORTED"}
+
+
+class CrtError(RuntimeError):
+    def __init__(self, code, what=""):
+        super().__init__(f"{what}: {_ERRORS.get(code, code)}")
+        self.code = code
+
+
+def build_native(force=False):
+    """Compile libcrt_amd.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", CSRC, "-j8", "-s"])
+    return LIB_PATH
+
+
+# ------------------------------------------------------------------ C structs (include/crt.h)
+class CrtRay(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("_pad0", C.c_float), ("dir", C.c_float * 3), ("_pad1", C.c_float),
+                ("time", C.c_float), ("mask", C.c_uint32), ("_pad2", C.c_uint32 * 2)]
+
+
+class CrtRayHit(C.Structure):
+    _fields_ = [("t", C.c_float), ("normal", C.c_float * 3), ("front_face", C.c_uint32), ("u", C.c_float),
+                ("v", C.c_float), ("geom_id", C.c_uint32), ("prim_id", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+class CrtTravStats(C.Structure):
+    _fields_ = [("queries", C.c_uint64 * 2), ("nodes", C.c_uint64 * 2), ("leaves", C.c_uint64 * 2),
+                ("packets", C.c_uint64 * 2), ("prims", C.c_uint64 * 2), ("accepted_hits", C.c_uint64),
+                ("instance_descents", C.c_uint64), ("rays", C.c_uint64)]
+
+    def as_dict(self):
+        d = {k: [int(getattr(self, k)[0]), int(getattr(self, k)[1])] for k in ("queries", "nodes", "leaves", "packets",
+                                                                                "prims")}
+        d.update(accepted_hits=int(self.accepted_hits), instance_descents=int(self.instance_descents),
+                 rays=int(self.rays))
+        return d
+
+    def algorithmic_bytes(self):
+        """48 (ray in) + 32 (hit out) per ray + 128/node + 16/leaf + 192/packet + 64/scalar
+        prim test + 128/accepted hit + 112/instance descent."""
+        n = sum
+        return (80 * int(self.rays) + 128 * n(self.nodes) + 16 * n(self.leaves) + 192 * n(self.packets) +
+                64 * n(self.prims) + 128 * int(self.accepted_hits) + 112 * int(self.instance_descents))
+
+
+_MAT_FIELDS = [
+    ("kind", C.c_uint32), ("thin_walled", C.c_uint32),
+    ("base_weight", C.c_float), ("base_color", C.c_float * 3), ("base_diffuse_roughness", C.c_float),
+    ("base_metalness", C.c_float),
+    ("specular_weight", C.c_float), ("specular_color", C.c_float * 3), ("specular_roughness", C.c_float),
+    ("specular_ior", C.c_float), ("specular_roughness_anisotropy", C.c_float),
+    ("transmission_weight", C.c_float), ("transmission_color", C.c_float * 3), ("transmission_depth", C.c_float),
+    ("transmission_scatter", C.c_float * 3), ("transmission_scatter_anisotropy", C.c_float),
+    ("transmission_dispersion_scale", C.c_float), ("transmission_dispersion_abbe_number", C.c_float),
+    ("subsurface_weight", C.c_float), ("subsurface_color", C.c_float * 3), ("subsurface_radius", C.c_float),
+    ("subsurface_radius_scale", C.c_float * 3), ("subsurface_scatter_anisotropy", C.c_float),
+    ("fuzz_weight", C.c_float), ("fuzz_color", C.c_float * 3), ("fuzz_roughness", C.c_float),
+    ("coat_weight", C.c_float), ("coat_color", C.c_float * 3), ("coat_roughness", C.c_float),
+    ("coat_roughness_anisotropy", C.c_float), ("coat_ior", C.c_float), ("coat_darkening", C.c_float),
+    ("thin_film_weight", C.c_float), ("thin_film_thickness", C.c_float), ("thin_film_ior", C.c_float),
+    ("emission_luminance", C.c_float), ("emission_color", C.c_float * 3),
+    ("geometry_opacity", C.c_float),
+]
+
+
+class CrtMaterial(C.Structure):
+    _fields_ = _MAT_FIELDS
+
+
+MAT_OPENPBR, MAT_EMISSIVE = 0, 1
+LIGHT_SPHERE, LIGHT_RECT = 0, 1
+STRATEGY = {"power": 0, "mis": 0, "balance": 1, "light": 2, "bsdf": 3}
+FILTER = {"box": 0, "triangle": 1}
+
+
+class CrtLight(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("geom_id", C.c_uint32), ("radiance", C.c_float * 3),
+                ("center", C.c_float * 3), ("radius", C.c_float), ("origin", C.c_float * 3),
+                ("edge_u", C.c_float * 3), ("edge_v", C.c_float * 3), ("normal", C.c_float * 3)]
+
+
+class CrtCamera(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("lower_left", C.c_float * 3), ("horizontal", C.c_float * 3),
+                ("vertical", C.c_float * 3), ("u", C.c_float * 3), ("v", C.c_float * 3), ("lens_radius", C.c_float)]
+
+
+class CrtRenderSettings(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("max_depth", C.c_uint32), ("frame", C.c_int32),
+                ("strategy", C.c_int32), ("filter_kind", C.c_int32), ("filter_radius", C.c_float),
+                ("variance_threshold", C.c_float)]
+
+
+class CrtRayStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("camera_rays", "closest_hit", "shadow_rays", "vertices", "rr_tested",
+                                          "rr_killed", "ended_escaped", "ended_depth")]
+
+    def total_rays(self):  # stats.rs:150-152
+        return int(self.closest_hit) + int(self.shadow_rays)
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+# Every symbol include/crt.h declares (checked by tests/test_abi.py against the header text).
+ABI_SYMBOLS = [
+    "crt_builder_new", "crt_builder_free", "crt_reserve", "crt_count", "crt_attach_triangles", "crt_attach_sphere",
+    "crt_attach_instance", "crt_attach_empty", "crt_set_triangles", "crt_set_sphere", "crt_set_instance", "crt_commit",
+    "crt_scene_retain", "crt_scene_release", "crt_scene_bounds", "crt_scene_geometry_count", "crt_scene_has_motion",
+    "crt_scene_primitive_count", "crt_scene_primitive_breakdown", "crt_scene_memory_footprint", "crt_scene_tree",
+    "crt_intersect1", "crt_occluded1", "crt_intersect_n", "crt_occluded_n", "crt_intersect_n_stats",
+    "crt_occluded_n_stats", "crt_material_default", "crt_camera_new", "crt_renderer_new", "crt_renderer_free",
+    "crt_renderer_pixel_count", "crt_renderer_pixel_indices", "crt_render_samples", "crt_film_resolve",
+    "crt_film_read", "crt_film_clear", "crt_render_stats", "crt_renderer_profile", "crt_renderer_profile_read",
+    "crt_render_samples_stats", "crt_version", "crt_device_info",
+]
+
+_lib = None
+
+
+def lib():
+    """Loads libcrt_amd.so. Raises if the HIP extension has not been built: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc, gfx950). "
+                           "crust-render_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    fp, up, vp = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_void_p
+    L.crt_version.restype = C.c_char_p
+    L.crt_device_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
+    L.crt_builder_new.restype = vp
+    L.crt_builder_free.argtypes = [vp]
+    L.crt_reserve.argtypes = [vp, C.c_size_t]
+    L.crt_count.restype = C.c_size_t
+    L.crt_count.argtypes = [vp]
+    L.crt_attach_triangles.argtypes = [vp, fp, C.c_size_t, up, C.c_size_t, fp, C.c_size_t, C.c_uint32, up]
+    L.crt_attach_sphere.argtypes = [vp, fp, C.c_float, C.c_uint32, up]
+    L.crt_attach_instance.argtypes = [vp, vp, fp, fp, C.c_uint32, up]
+    L.crt_attach_empty.argtypes = [vp, C.c_uint32, up]
+    L.crt_set_triangles.argtypes = [vp, C.c_uint32, fp, C.c_size_t, up, C.c_size_t, fp, C.c_size_t]
+    L.crt_set_sphere.argtypes = [vp, C.c_uint32, fp, C.c_float]
+    L.crt_set_instance.argtypes = [vp, C.c_uint32, vp, fp, fp]
+    L.crt_commit.restype = vp
+    L.crt_commit.argtypes = [vp]
+    L.crt_scene_retain.argtypes = [vp]
+    L.crt_scene_release.argtypes = [vp]
+    L.crt_scene_bounds.argtypes = [vp, fp]
+    L.crt_scene_geometry_count.restype = C.c_uint32
+    L.crt_scene_geometry_count.argtypes = [vp]
+    L.crt_scene_has_motion.argtypes = [vp]
+    L.crt_scene_primitive_count.restype = C.c_size_t
+    L.crt_scene_primitive_count.argtypes = [vp]
+    L.crt_scene_primitive_breakdown.argtypes = [vp, C.POINTER(C.c_size_t)]
+    L.crt_scene_memory_footprint.argtypes = [vp, C.POINTER(C.c_size_t)]
+    L.crt_scene_tree.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                 C.POINTER(up)]
+    L.crt_intersect1.argtypes = [vp, C.POINTER(CrtRay), C.c_float, C.c_float, C.POINTER(CrtRayHit)]
+    L.crt_occluded1.argtypes = [vp, C.POINTER(CrtRay), C.c_float, C.c_float]
+    L.crt_intersect_n.argtypes = [vp, vp, C.c_size_t, C.c_float, C.c_float, vp, vp]
+    L.crt_occluded_n.argtypes = [vp, vp, C.c_size_t, C.c_float, C.c_float, vp, vp]
+    L.crt_intersect_n_stats.argtypes = [vp, vp, C.c_size_t, C.c_float, C.c_float, vp, vp, C.POINTER(CrtTravStats)]
+    L.crt_occluded_n_stats.argtypes = [vp, vp, C.c_size_t, C.c_float, C.c_float, vp, vp, C.POINTER(CrtTravStats)]
+    L.crt_material_default.argtypes = [C.POINTER(CrtMaterial)]
+    if hasattr(L, "crt_renderer_new"):
+        L.crt_camera_new.argtypes = [C.POINTER(CrtCamera), fp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float]
+        L.crt_renderer_new.restype = vp
+        L.crt_renderer_new.argtypes = [vp, C.POINTER(CrtMaterial), C.c_size_t, C.POINTER(CrtLight), C.c_size_t,
+                                       C.POINTER(CrtCamera), C.POINTER(CrtRenderSettings), C.c_uint32, C.c_uint32]
+        L.crt_renderer_free.argtypes = [vp]
+        L.crt_renderer_pixel_count.restype = C.c_size_t
+        L.crt_renderer_pixel_count.argtypes = [vp]
+        L.crt_renderer_pixel_indices.argtypes = [vp, up]
+        L.crt_render_samples.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+        L.crt_film_resolve.argtypes = [vp, vp, vp]
+        L.crt_film_read.argtypes = [vp, fp]
+        L.crt_film_clear.argtypes = [vp, vp]
+        L.crt_render_stats.argtypes = [vp, C.POINTER(CrtRayStats)]
+        L.crt_renderer_profile.argtypes = [vp, C.c_int]
+        L.crt_renderer_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        L.crt_render_samples_stats.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.POINTER(CrtTravStats)]
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc < 0:
+        raise CrtError(rc, what)
+    return rc
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+
+
+def _up(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32)) if a is not None else None
+
+
+IDENTITY12 = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], dtype=np.float32)
+
+
+def affine(m3=None, t=(0, 0, 0)):
+    """glam Affine3A as 12 floats: matrix3 columns x, y, z then translation."""
+    m = np.eye(3, dtype=np.float32) if m3 is None else np.asarray(m3, dtype=np.float32)
+    return np.concatenate([m[:, 0], m[:, 1], m[:, 2], np.asarray(t, dtype=np.float32)]).astype(np.float32)
+
+
+# ------------------------------------------------------------------ crust_rt mirror
+class Ray:
+    """crust_rt::Ray (ray.rs:18-55)."""
+
+    def __init__(self, origin, dir, time=0.0, mask=MASK_ALL):
+        self.origin, self.dir, self.time, self.mask = origin, dir, time, mask
+
+    def c(self):
+        r = CrtRay()
+        r.origin[:] = [float(x) for x in self.origin]
+        r.dir[:] = [float(x) for x in self.dir]
+        r.time = self.time
+        r.mask = self.mask
+        return r
+
+
+RAY_DTYPE = np.dtype([("origin", np.float32, 3), ("_p0", np.float32), ("dir", np.float32, 3), ("_p1", np.float32),
+                      ("time", np.float32), ("mask", np.uint32), ("_p2", np.uint32, 2)])
+HIT_DTYPE = np.dtype([("t", np.float32), ("normal", np.float32, 3), ("front_face", np.uint32), ("u", np.float32),
+                      ("v", np.float32), ("geom_id", np.uint32), ("prim_id", np.uint32), ("_pad", np.uint32)])
+assert RAY_DTYPE.itemsize == 48 and HIT_DTYPE.itemsize == 40
+
+
+def pack_rays(rays8):
+    """[n, 8] float32 (o, d, time, mask bits) -> CrtRay records."""
+    rays8 = np.ascontiguousarray(rays8, dtype=np.float32).reshape(-1, 8)
+    out = np.zeros(rays8.shape[0], dtype=RAY_DTYPE)
+    out["origin"] = rays8[:, 0:3]
+    out["dir"] = rays8[:, 3:6]
+    out["time"] = rays8[:, 6]
+    out["mask"] = rays8[:, 7].view(np.uint32)
+    return out
+
+
+class Scene:
+    """crust_rt::Scene (scene.rs:345-479): immutable, ref-counted."""
+
+    def __init__(self, handle, keep=()):
+        if not handle:
+            raise RuntimeError("crt_commit failed")
+        self.h = handle
+        self._keep = list(keep)
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().crt_scene_release(self.h)
+        except Exception:
+            pass
+
+    def intersect(self, ray, t_min, t_max):
+        h = CrtRayHit()
+        rc = _check(lib().crt_intersect1(self.h, C.byref(ray.c()), t_min, t_max, C.byref(h)), "crt_intersect1")
+        return h if rc == 1 else None
+
+    def occluded(self, ray, t_min, t_max):
+        return _check(lib().crt_occluded1(self.h, C.byref(ray.c()), t_min, t_max), "crt_occluded1") == 1
+
+    def bounds(self):
+        out = np.zeros(6, dtype=np.float32)
+        return out if _check(lib().crt_scene_bounds(self.h, _fp(out)), "crt_scene_bounds") == 1 else None
+
+    def geometry_count(self):
+        return lib().crt_scene_geometry_count(self.h)
+
+    def has_motion(self):
+        return bool(lib().crt_scene_has_motion(self.h))
+
+    def primitive_count(self):
+        return lib().crt_scene_primitive_count(self.h)
+
+    def primitive_breakdown(self):
+        out = (C.c_size_t * 5)()
+        _check(lib().crt_scene_primitive_breakdown(self.h, out), "crt_scene_primitive_breakdown")
+        return dict(zip(("triangles", "spheres", "curve_segments", "cubic_curve_spans", "instances"), map(int, out)))
+
+    def memory_footprint(self):
+        out = (C.c_size_t * 6)()
+        _check(lib().crt_scene_memory_footprint(self.h, out), "crt_scene_memory_footprint")
+        return dict(zip(("prim_nodes", "boxed_prims", "bvh_nodes", "leaves", "packets", "indices"), map(int, out)))
+
+    def tree(self):
+        """Host copies of the committed tree as uint32 words: nodes[n,32], leaves[n,4], packets[n,48], indices[n]."""
+        counts = (C.c_size_t * 5)()
+        pn, pl, pp = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        pi = C.POINTER(C.c_uint32)()
+        _check(lib().crt_scene_tree(self.h, counts, C.byref(pn), C.byref(pl), C.byref(pp), C.byref(pi)),
+               "crt_scene_tree")
+
+        def grab(ptr, n, words):
+            if n == 0:
+                return np.zeros((0, words), dtype=np.uint32)
+            buf = C.cast(ptr, C.POINTER(C.c_uint32 * (n * words))).contents
+            return np.frombuffer(buf, dtype=np.uint32).reshape(n, words).copy()
+
+        return (grab(pn, counts[0], 32), grab(pl, counts[1], 4), grab(pp, counts[2], 48),
+                grab(pi, counts[3], 1).reshape(-1), dict(nodes=counts[0], leaves=counts[1], packets=counts[2],
+                                                         indices=counts[3], prims=counts[4]))
+
+    # ---- batched device queries (torch tensors hold the HBM buffers) ----
+    def intersect_n(self, d_rays, t_min, t_max, d_hits=None, stream=None, stats=None):
+        """d_rays: torch uint8/any tensor on cuda holding n CrtRay records (48 B each). Returns d_hits (n*40 B)."""
+        import torch
+        n = d_rays.numel() * d_rays.element_size() // 48
+        if d_hits is None:
+            d_hits = torch.empty(n * 40, dtype=torch.uint8, device=d_rays.device)
+        sp = _stream_ptr(stream)
+        if stats is None:
+            _check(lib().crt_intersect_n(self.h, d_rays.data_ptr(), n, t_min, t_max, d_hits.data_ptr(), sp),
+                   "crt_intersect_n")
+        else:
+            _check(lib().crt_intersect_n_stats(self.h, d_rays.data_ptr(), n, t_min, t_max, d_hits.data_ptr(), sp,
+                                               C.byref(stats)), "crt_intersect_n_stats")
+        return d_hits
+
+    def occluded_n(self, d_rays, t_min, t_max, d_out=None, stream=None, stats=None):
+        import torch
+        n = d_rays.numel() * d_rays.element_size() // 48
+        if d_out is None:
+            d_out = torch.empty(n, dtype=torch.int32, device=d_rays.device)
+        sp = _stream_ptr(stream)
+        if stats is None:
+            _check(lib().crt_occluded_n(self.h, d_rays.data_ptr(), n, t_min, t_max, d_out.data_ptr(), sp),
+                   "crt_occluded_n")
+        else:
+            _check(lib().crt_occluded_n_stats(self.h, d_rays.data_ptr(), n, t_min, t_max, d_out.data_ptr(), sp,
+                                              C.byref(stats)), "crt_occluded_n_stats")
+        return d_out
+
+
+def _stream_ptr(stream):
+    """HIP stream handle for the C ABI. Defaults to torch's current stream so launches order with torch ops."""
+    if stream is None:
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if isinstance(stream, int):
+        return C.c_void_p(stream)
+    return C.c_void_p(stream.cuda_stream)
+
+
+def rays_to_device(rays8, device="cuda:0"):
+    import torch
+    rec = pack_rays(rays8)
+    return torch.from_numpy(rec.view(np.uint8).reshape(-1)).to(device)
+
+
+def hits_to_host(d_hits):
+    return d_hits.cpu().numpy().view(HIT_DTYPE)
+
+
+class SceneBuilder:
+    """crust_rt::SceneBuilder (scene.rs:147-342). Geometry variants are the attach_* methods
+    (Geometry::TriangleMesh / Sphere / Instance, scene.rs:87-122)."""
+
+    def __init__(self):
+        self.h = lib().crt_builder_new()
+        self._keep = []
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().crt_builder_free(self.h)
+        except Exception:
+            pass
+
+    def reserve(self, additional):
+        _check(lib().crt_reserve(self.h, additional), "crt_reserve")
+
+    def count(self):
+        return lib().crt_count(self.h)
+
+    @staticmethod
+    def _mesh(verts, idx, normals):
+        verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
+        idx = np.ascontiguousarray(idx, dtype=np.uint32).reshape(-1, 3)
+        nrm = None if normals is None else np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3)
+        return verts, idx, nrm
+
+    def attach_triangles(self, verts, idx, normals=None, mask=MASK_ALL):
+        v, i, n = self._mesh(verts, idx, normals)
+        gid = C.c_uint32()
+        _check(lib().crt_attach_triangles(self.h, _fp(v), v.shape[0], _up(i), i.shape[0], _fp(n),
+                                          0 if n is None else n.shape[0], mask, C.byref(gid)), "crt_attach_triangles")
+        return gid.value
+
+    def attach_sphere(self, center, radius, mask=MASK_ALL):
+        c = np.asarray(center, dtype=np.float32)
+        gid = C.c_uint32()
+        _check(lib().crt_attach_sphere(self.h, _fp(c), radius, mask, C.byref(gid)), "crt_attach_sphere")
+        return gid.value
+
+    def attach_instance(self, scene, l2w=IDENTITY12, l2w_end=None, mask=MASK_ALL):
+        a = np.ascontiguousarray(l2w, dtype=np.float32)
+        e = None if l2w_end is None else np.ascontiguousarray(l2w_end, dtype=np.float32)
+        gid = C.c_uint32()
+        _check(lib().crt_attach_instance(self.h, scene.h, _fp(a), _fp(e), mask, C.byref(gid)), "crt_attach_instance")
+        self._keep.append(scene)
+        return gid.value
+
+    def attach_empty(self, mask=MASK_ALL):
+        gid = C.c_uint32()
+        _check(lib().crt_attach_empty(self.h, mask, C.byref(gid)), "crt_attach_empty")
+        return gid.value
+
+    def set_triangles(self, gid, verts, idx, normals=None):
+        v, i, n = self._mesh(verts, idx, normals)
+        _check(lib().crt_set_triangles(self.h, gid, _fp(v), v.shape[0], _up(i), i.shape[0], _fp(n),
+                                       0 if n is None else n.shape[0]), "crt_set_triangles")
+
+    def set_sphere(self, gid, center, radius):
+        c = np.asarray(center, dtype=np.float32)
+        _check(lib().crt_set_sphere(self.h, gid, _fp(c), radius), "crt_set_sphere")
+
+    def set_instance(self, gid, scene, l2w=IDENTITY12, l2w_end=None):
+        a = np.ascontiguousarray(l2w, dtype=np.float32)
+        e = None if l2w_end is None else np.ascontiguousarray(l2w_end, dtype=np.float32)
+        _check(lib().crt_set_instance(self.h, gid, scene.h, _fp(a), _fp(e)), "crt_set_instance")
+        self._keep.append(scene)
+
+    def commit(self):
+        h, self.h = self.h, None
+        return Scene(lib().crt_commit(h), self._keep)
+
+
+def default_material():
+    m = CrtMaterial()
+    lib().crt_material_default(C.byref(m))
+    return m
+
+
+def diffuse_material(rgb):  # OpenPBR::diffuse, openpbr.rs:177-183
+    m = default_material()
+    m.base_color[:] = [float(x) for x in rgb]
+    m.specular_weight = 0.0
+    return m
+
+
+def emissive_material(rgb):  # Emissive::new, emissive.rs:16-19
+    m = default_material()
+    m.kind = MAT_EMISSIVE
+    m.emission_color[:] = [float(x) for x in rgb]
+    m.emission_luminance = 1.0
+    return m

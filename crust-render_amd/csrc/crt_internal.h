@@ -1,0 +1,191 @@
+// Internal host/device declarations of libcrt_amd.so (not part of the ABI).
+//
+// Host side (C++17): geometry table, deterministic SBVH -> BVH4 build, flattening of a committed
+// scene and everything it instances into ONE device image with absolute indices.
+// Device side (HIP, gfx950): see kernels/.
+#pragma once
+
+#include <atomic>
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "../../include/crt.h"
+
+namespace crt {
+
+// ---------------------------------------------------------------------------------------------
+// Small float3 with glam Vec3A (SSE2) semantics. Compiled -ffp-contract=off.
+// ---------------------------------------------------------------------------------------------
+struct F3 {
+  float x, y, z;
+  float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+  float &at(int i) { return i == 0 ? x : (i == 1 ? y : z); }
+};
+inline F3 f3(float x, float y, float z) { return F3{x, y, z}; }
+inline F3 operator+(F3 a, F3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline F3 operator-(F3 a, F3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline F3 operator*(F3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline F3 operator-(F3 a) { return {-a.x, -a.y, -a.z}; }
+inline float sse_min(float a, float b) { return a < b ? a : b; }  // minps
+inline float sse_max(float a, float b) { return a > b ? a : b; }  // maxps
+inline F3 vmin(F3 a, F3 b) { return {sse_min(a.x, b.x), sse_min(a.y, b.y), sse_min(a.z, b.z)}; }
+inline F3 vmax(F3 a, F3 b) { return {sse_max(a.x, b.x), sse_max(a.y, b.y), sse_max(a.z, b.z)}; }
+inline float dot(F3 a, F3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline F3 cross(F3 a, F3 b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+
+struct Aabb { F3 mn, mx; };
+struct Affine { F3 x, y, z, t; };  // glam Affine3A: matrix3 columns + translation
+struct Mat3 { F3 x, y, z; };
+
+Affine affine_inverse(const Affine &a);
+Mat3 mat3_transpose(const Mat3 &m);
+F3 affine_point(const Affine &a, F3 p);
+F3 affine_vector(const Affine &a, F3 p);
+Aabb transformed_aabb(const Aabb &local, const Affine &m);  // prim.rs:298-319
+
+// ---------------------------------------------------------------------------------------------
+// Committed-tree records. These are the reference's layouts (bvh.rs:196-227, triangle.rs:182-196)
+// and also the device layouts: one node = one 128-byte line, one packet = 192 bytes.
+// ---------------------------------------------------------------------------------------------
+struct alignas(16) WideNode {
+  float bmin[3][4];
+  float bmax[3][4];
+  uint32_t child[4];
+  uint32_t flags;  // bits 0-3 valid lane, bits 4-7 leaf lane
+  uint32_t pad[3];
+};
+static_assert(sizeof(WideNode) == 128, "bvh.rs:1613-1616");
+
+struct Leaf { uint32_t pkt_first, pkt_count, idx_first, idx_count; };
+static_assert(sizeof(Leaf) == 16, "bvh.rs:220-227");
+
+struct alignas(16) Tri4 {
+  float v[3][3][4];  // [vertex][axis][lane]
+  uint32_t prim[4];
+  uint32_t active, mask_and, mask_or;
+  uint32_t masks[4];
+  // Device extra (the reference's padding word): bit k set iff lane k can produce a normal, i.e. it
+  // has shading normals or a non-zero geometric cross product (prim.rs:76-86 rejects the others).
+  uint32_t normal_ok;
+};
+static_assert(sizeof(Tri4) == 192, "triangle.rs:182-196");
+
+enum PrimKind : uint32_t { PRIM_TRI = 0, PRIM_SPHERE = 1, PRIM_INSTANCE = 2 };
+
+struct Scene;
+
+// Host primitive (prim.rs:60-70, :125-130, :261-280).
+struct Prim {
+  PrimKind kind;
+  uint32_t geom_id, prim_id, mask;
+  F3 v0, v1, v2;
+  bool has_normals;
+  F3 n0, n1, n2;
+  F3 center;
+  float radius;
+  std::shared_ptr<Scene> scene;
+  Affine l2w, w2l;
+  Mat3 normal_mat;
+  bool has_end;
+  Affine l2w_end;
+  Aabb bounds;
+};
+
+struct Bvh {
+  std::vector<WideNode> wide;
+  std::vector<Leaf> leaves;
+  std::vector<Tri4> packets;
+  std::vector<uint32_t> indices;
+  std::vector<Prim> prims;
+  bool has_bbox = false;
+  Aabb root_bbox{};
+};
+
+Aabb prim_bbox(const Prim &p);
+void build_bvh(Bvh &out, std::vector<Prim> &&prims);  // bvh.rs:300-327
+
+// ---------------------------------------------------------------------------------------------
+// Device image (HBM): the queried scene and every scene it instances, flattened.
+// ---------------------------------------------------------------------------------------------
+struct DevPrim {  // 64 bytes
+  uint32_t kind, geom_id, prim_id, mask;
+  float d[12];  // tri: v0 v1 v2 (9) + [9]=smooth-normal slot (u32 bits, ~0 = none)
+                // sphere: center (3), radius | instance: [0] = instance slot (u32 bits)
+};
+static_assert(sizeof(DevPrim) == 64, "");
+
+struct DevInstance {  // 192 bytes
+  float w2l[12];      // cached world-to-local at time 0 (prim.rs:266)
+  float nmat[9];      // inverse transpose (prim.rs:267)
+  uint32_t root;      // absolute node index of the instanced scene's root
+  uint32_t has_packets;
+  uint32_t has_end;   // transform motion blur (prim.rs:276)
+  float l2w[12];
+  float l2w_end[12];
+};
+static_assert(sizeof(DevInstance) == 192, "");
+
+struct DevScene {
+  const WideNode *nodes;
+  const Leaf *leaves;
+  const Tri4 *packets;
+  const uint32_t *indices;
+  const DevPrim *prims;
+  const DevInstance *instances;
+  const float *normals;  // 9 floats per smooth triangle
+  uint32_t root;         // CRT_INVALID_ID when the scene is empty (bvh.rs:442-444)
+  uint32_t has_packets;
+};
+
+struct DeviceImage {
+  void *blob = nullptr;
+  size_t bytes[7] = {0, 0, 0, 0, 0, 0, 0};  // nodes, leaves, packets, indices, prims, instances, normals
+  DevScene view{};
+  ~DeviceImage();
+};
+
+struct Scene : std::enable_shared_from_this<Scene> {
+  Bvh bvh;
+  uint32_t n_geoms = 0;
+  bool has_motion = false;
+  std::mutex dev_mu;
+  std::unique_ptr<DeviceImage> dev;  // built on first query
+  int ensure_device();               // CRT_OK or CRT_ERR_NO_DEVICE
+};
+
+enum GeomKind { G_MESH, G_SPHERE, G_INSTANCE };
+struct Geom {
+  GeomKind kind = G_MESH;
+  uint32_t mask = CRT_MASK_ALL;
+  std::vector<float> verts;
+  std::vector<uint32_t> idx;
+  bool has_normals = false;
+  std::vector<float> normals;
+  F3 center{0, 0, 0};
+  float radius = 0;
+  std::shared_ptr<Scene> scene;
+  Affine l2w{};
+  bool has_end = false;
+  Affine l2w_end{};
+};
+
+struct Builder { std::vector<Geom> geoms; };
+
+std::shared_ptr<Scene> commit(Builder &&b);  // scene.rs:226-341
+
+// ---------------------------------------------------------------------------------------------
+// Device launches (kernels/traverse.hip)
+// ---------------------------------------------------------------------------------------------
+int launch_intersect_n(const DevScene &s, const CrtRay *d_rays, size_t n, float t_min, float t_max, CrtRayHit *d_hits,
+                       void *stream, CrtTravStats *d_stats);
+int launch_occluded_n(const DevScene &s, const CrtRay *d_rays, size_t n, float t_min, float t_max, uint32_t *d_out,
+                      void *stream, CrtTravStats *d_stats);
+int device_ok();
+
+}  // namespace crt
+
+struct CrtScene { std::shared_ptr<crt::Scene> p; std::atomic<int> refs{1}; };
+struct CrtBuilder { crt::Builder b; };

@@ -1,0 +1,158 @@
+// Batched Scene::intersect / Scene::occluded kernels (scene.rs:354-372) over the device image.
+// Compile with -ffp-contract=off (see traverse.hip.h).
+#include "traverse.hip.h"
+
+namespace crt {
+
+using namespace dev;
+
+namespace {
+
+__device__ __forceinline__ void flush_stats(const LaneStats &st, CrtTravStats *out, uint32_t rays) {
+  // One atomic per counter per wave: sum across the 64 lanes first.
+  auto wave_sum = [](uint32_t v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+  };
+  const bool lead = (threadIdx.x & 63) == 0;
+  for (int k = 0; k < 2; k++) {
+    uint32_t a = wave_sum(st.queries[k]), b = wave_sum(st.nodes[k]), c = wave_sum(st.leaves[k]);
+    uint32_t d = wave_sum(st.packets[k]), e = wave_sum(st.prims[k]);
+    if (lead) {
+      atomicAdd((unsigned long long *)&out->queries[k], (unsigned long long)a);
+      atomicAdd((unsigned long long *)&out->nodes[k], (unsigned long long)b);
+      atomicAdd((unsigned long long *)&out->leaves[k], (unsigned long long)c);
+      atomicAdd((unsigned long long *)&out->packets[k], (unsigned long long)d);
+      atomicAdd((unsigned long long *)&out->prims[k], (unsigned long long)e);
+    }
+  }
+  uint32_t a = wave_sum(st.accepted), b = wave_sum(st.descents), c = wave_sum(rays);
+  if (lead) {
+    atomicAdd((unsigned long long *)&out->accepted_hits, (unsigned long long)a);
+    atomicAdd((unsigned long long *)&out->instance_descents, (unsigned long long)b);
+    atomicAdd((unsigned long long *)&out->rays, (unsigned long long)c);
+  }
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void intersect_n_kernel(DevScene S, const CrtRay *__restrict__ rays, size_t n,
+                                                            float t_min, float t_max, CrtRayHit *__restrict__ hits,
+                                                            uint32_t *__restrict__ err_out, CrtTravStats *stats) {
+  __shared__ uint32_t stack[kStackLds * kBlock];
+  LaneStats st = {};
+  uint32_t err = 0, done = 0;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const float4 *rp = reinterpret_cast<const float4 *>(rays + i);
+    const float4 o = rp[0], d = rp[1], tm = rp[2];
+    Hit h;
+    const bool hit = traverse<false, STATS>(S, o.x, o.y, o.z, d.x, d.y, d.z, tm.x, __float_as_uint(tm.y), t_min, t_max,
+                                            h, &stack[threadIdx.x], err, st);
+    CrtRayHit out;
+    if (hit) {  // scene.rs:355-365
+      const bool front = dot3(d.x, d.y, d.z, h.nx, h.ny, h.nz) < 0.0f;
+      out.t = h.t;
+      out.normal[0] = front ? h.nx : -h.nx;
+      out.normal[1] = front ? h.ny : -h.ny;
+      out.normal[2] = front ? h.nz : -h.nz;
+      out.front_face = front ? 1u : 0u;
+      out.u = h.u; out.v = h.v; out.geom_id = h.geom; out.prim_id = h.prim; out._pad = 0;
+    } else {
+      out.t = 0.0f; out.normal[0] = out.normal[1] = out.normal[2] = 0.0f; out.front_face = 0;
+      out.u = out.v = 0.0f; out.geom_id = CRT_INVALID_ID; out.prim_id = CRT_INVALID_ID; out._pad = 0;
+    }
+    hits[i] = out;
+    done++;
+  }
+  if (err) atomicOr(err_out, err);
+  if (STATS) flush_stats(st, stats, done);
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void occluded_n_kernel(DevScene S, const CrtRay *__restrict__ rays, size_t n,
+                                                           float t_min, float t_max, uint32_t *__restrict__ out,
+                                                           uint32_t *__restrict__ err_out, CrtTravStats *stats) {
+  __shared__ uint32_t stack[kStackLds * kBlock];
+  LaneStats st = {};
+  uint32_t err = 0, done = 0;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const float4 *rp = reinterpret_cast<const float4 *>(rays + i);
+    const float4 o = rp[0], d = rp[1], tm = rp[2];
+    Hit h;
+    const bool occ = traverse<true, STATS>(S, o.x, o.y, o.z, d.x, d.y, d.z, tm.x, __float_as_uint(tm.y), t_min, t_max, h,
+                                           &stack[threadIdx.x], err, st);
+    out[i] = occ ? 1u : 0u;
+    done++;
+  }
+  if (err) atomicOr(err_out, err);
+  if (STATS) flush_stats(st, stats, done);
+}
+
+uint32_t *device_err_word() {
+  static uint32_t *p = [] {
+    uint32_t *q = nullptr;
+    if (hipMalloc(&q, sizeof(uint32_t)) != hipSuccess) return (uint32_t *)nullptr;
+    (void)hipMemset(q, 0, sizeof(uint32_t));
+    return q;
+  }();
+  return p;
+}
+
+int grid_for(size_t n) {
+  static int cus = [] {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }();
+  size_t need = (n + kBlock - 1) / kBlock;
+  size_t cap = (size_t)cus * 8;  // persistent grid: up to 8 workgroups (32 waves) per CU, grid-stride beyond
+  return (int)(need < cap ? (need ? need : 1) : cap);
+}
+
+}  // namespace
+
+int traversal_error_check(void *stream) {
+  uint32_t *e = device_err_word();
+  if (!e) return CRT_ERR_NO_DEVICE;
+  uint32_t h = 0;
+  if (hipMemcpyAsync(&h, e, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return CRT_ERR_NO_DEVICE;
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return CRT_ERR_NO_DEVICE;
+  if (h) {
+    (void)hipMemsetAsync(e, 0, sizeof h, (hipStream_t)stream);
+    return CRT_ERR_STACK;
+  }
+  return CRT_OK;
+}
+
+int launch_intersect_n(const DevScene &s, const CrtRay *d_rays, size_t n, float t_min, float t_max, CrtRayHit *d_hits,
+                       void *stream, CrtTravStats *d_stats) {
+  if (n == 0) return CRT_OK;
+  uint32_t *e = device_err_word();
+  if (!e) return CRT_ERR_NO_DEVICE;
+  const int grid = grid_for(n);
+  if (d_stats)
+    hipLaunchKernelGGL(intersect_n_kernel<true>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, s, d_rays, n, t_min,
+                       t_max, d_hits, e, d_stats);
+  else
+    hipLaunchKernelGGL(intersect_n_kernel<false>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, s, d_rays, n, t_min,
+                       t_max, d_hits, e, d_stats);
+  return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_NO_DEVICE;
+}
+
+int launch_occluded_n(const DevScene &s, const CrtRay *d_rays, size_t n, float t_min, float t_max, uint32_t *d_out,
+                      void *stream, CrtTravStats *d_stats) {
+  if (n == 0) return CRT_OK;
+  uint32_t *e = device_err_word();
+  if (!e) return CRT_ERR_NO_DEVICE;
+  const int grid = grid_for(n);
+  if (d_stats)
+    hipLaunchKernelGGL(occluded_n_kernel<true>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, s, d_rays, n, t_min,
+                       t_max, d_out, e, d_stats);
+  else
+    hipLaunchKernelGGL(occluded_n_kernel<false>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, s, d_rays, n, t_min,
+                       t_max, d_out, e, d_stats);
+  return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_NO_DEVICE;
+}
+
+}  // namespace crt

@@ -1,0 +1,279 @@
+// SceneBuilder::commit and the device image.
+//
+// commit() follows crates/crust-rt/src/scene.rs:226-341: geometries expand to primitives in attach order,
+// out-of-range triangles and empty instanced scenes are skipped silently, instances cache w2l and the
+// inverse transpose. The device image flattens the queried scene plus everything it instances (to any
+// depth) into seven HBM arrays with absolute indices, so the kernel follows an instance by jumping to
+// another root node in the same arrays.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <unordered_map>
+
+#include "crt_internal.h"
+
+namespace crt {
+
+// ---- glam Affine3A / Mat3A (SSE2 code paths) ----
+static F3 mat3_mul(const Mat3 &m, F3 r) {
+  F3 res = m.x * r.x;
+  res = res + m.y * r.y;
+  res = res + m.z * r.z;
+  return res;
+}
+Mat3 mat3_transpose(const Mat3 &m) {
+  return {f3(m.x.x, m.y.x, m.z.x), f3(m.x.y, m.y.y, m.z.y), f3(m.x.z, m.y.z, m.z.z)};
+}
+static Mat3 mat3_inverse(const Mat3 &m) {
+  F3 t0 = cross(m.y, m.z), t1 = cross(m.z, m.x), t2 = cross(m.x, m.y);
+  float det = dot(m.z, t2);
+  float inv = 1.0f / det;
+  return mat3_transpose(Mat3{t0 * inv, t1 * inv, t2 * inv});
+}
+Affine affine_inverse(const Affine &a) {
+  Mat3 inv = mat3_inverse(Mat3{a.x, a.y, a.z});
+  F3 t = -mat3_mul(inv, a.t);
+  return {inv.x, inv.y, inv.z, t};
+}
+F3 affine_point(const Affine &a, F3 p) { return mat3_mul(Mat3{a.x, a.y, a.z}, p) + a.t; }
+F3 affine_vector(const Affine &a, F3 p) { return mat3_mul(Mat3{a.x, a.y, a.z}, p); }
+
+Aabb transformed_aabb(const Aabb &local, const Affine &m) {  // prim.rs:298-319
+  const float inf = __builtin_inff();
+  F3 mn = f3(inf, inf, inf), mx = f3(-inf, -inf, -inf);
+  for (int i = 0; i < 8; i++) {
+    F3 corner = f3((i & 1) == 0 ? local.mn.x : local.mx.x, (i & 2) == 0 ? local.mn.y : local.mx.y,
+                   (i & 4) == 0 ? local.mn.z : local.mx.z);
+    F3 p = affine_point(m, corner);
+    mn = vmin(mn, p);
+    mx = vmax(mx, p);
+  }
+  constexpr float PAD = 1e-4f;
+  for (int a = 0; a < 3; a++)
+    if (mx[a] - mn[a] < PAD) { mn.at(a) -= PAD; mx.at(a) += PAD; }
+  return {mn, mx};
+}
+
+std::shared_ptr<Scene> commit(Builder &&b) {  // scene.rs:226-341
+  auto scene = std::make_shared<Scene>();
+  scene->n_geoms = uint32_t(b.geoms.size());
+  size_t total = 0;
+  for (const Geom &g : b.geoms) total += g.kind == G_MESH ? g.idx.size() / 3 : 1;
+  std::vector<Prim> prims;
+  prims.reserve(total);
+  bool has_motion = false;
+  for (size_t gi = 0; gi < b.geoms.size(); gi++) {
+    Geom &g = b.geoms[gi];
+    const uint32_t geom_id = uint32_t(gi);
+    switch (g.kind) {
+      case G_MESH: {
+        const size_t nv = g.verts.size() / 3, nn = g.normals.size() / 3, nt = g.idx.size() / 3;
+        auto vert = [&](const std::vector<float> &a, size_t i) { return f3(a[3 * i], a[3 * i + 1], a[3 * i + 2]); };
+        for (size_t t = 0; t < nt; t++) {
+          size_t i0 = g.idx[3 * t], i1 = g.idx[3 * t + 1], i2 = g.idx[3 * t + 2];
+          if (i0 >= nv || i1 >= nv || i2 >= nv) continue;  // scene.rs:251-253
+          Prim p{};
+          p.kind = PRIM_TRI;
+          p.geom_id = geom_id;
+          p.prim_id = uint32_t(t);
+          p.mask = g.mask;
+          p.v0 = vert(g.verts, i0);
+          p.v1 = vert(g.verts, i1);
+          p.v2 = vert(g.verts, i2);
+          if (g.has_normals && i0 < nn && i1 < nn && i2 < nn) {  // scene.rs:254-257
+            p.has_normals = true;
+            p.n0 = vert(g.normals, i0);
+            p.n1 = vert(g.normals, i1);
+            p.n2 = vert(g.normals, i2);
+          }
+          prims.push_back(std::move(p));
+        }
+        break;
+      }
+      case G_SPHERE: {
+        Prim p{};
+        p.kind = PRIM_SPHERE;
+        p.geom_id = geom_id;
+        p.mask = g.mask;
+        p.center = g.center;
+        p.radius = g.radius;
+        prims.push_back(std::move(p));
+        break;
+      }
+      case G_INSTANCE: {
+        if (!g.scene || !g.scene->bvh.has_bbox) break;  // empty instanced scene (scene.rs:307-309)
+        const Aabb inner = g.scene->bvh.root_bbox;
+        Prim p{};
+        p.kind = PRIM_INSTANCE;
+        p.geom_id = geom_id;
+        p.mask = g.mask;
+        p.scene = g.scene;
+        p.l2w = g.l2w;
+        p.w2l = affine_inverse(g.l2w);
+        p.normal_mat = mat3_transpose(Mat3{p.w2l.x, p.w2l.y, p.w2l.z});
+        p.has_end = g.has_end;
+        p.l2w_end = g.l2w_end;
+        if (g.has_end) {
+          Aabb a = transformed_aabb(inner, g.l2w), e = transformed_aabb(inner, g.l2w_end);
+          p.bounds = Aabb{vmin(a.mn, e.mn), vmax(a.mx, e.mx)};
+        } else {
+          p.bounds = transformed_aabb(inner, g.l2w);
+        }
+        has_motion |= g.has_end || g.scene->has_motion;  // scene.rs:322
+        prims.push_back(std::move(p));
+        break;
+      }
+    }
+  }
+  scene->has_motion = has_motion;
+  build_bvh(scene->bvh, std::move(prims));
+  return scene;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device image
+// ---------------------------------------------------------------------------------------------
+DeviceImage::~DeviceImage() {
+  if (blob) (void)hipFree(blob);
+}
+
+int device_ok() {
+  static int ok = [] {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+    return 1;
+  }();
+  return ok;
+}
+
+namespace {
+struct Flat {
+  std::vector<WideNode> nodes;
+  std::vector<Leaf> leaves;
+  std::vector<Tri4> packets;
+  std::vector<uint32_t> indices;
+  std::vector<DevPrim> prims;
+  std::vector<DevInstance> instances;
+  std::vector<float> normals;
+  struct Placed { uint32_t root; uint32_t has_packets; };
+  std::unordered_map<const Scene *, Placed> placed;
+};
+
+void put_affine(float out[12], const Affine &a) {
+  const float v[12] = {a.x.x, a.x.y, a.x.z, a.y.x, a.y.y, a.y.z, a.z.x, a.z.y, a.z.z, a.t.x, a.t.y, a.t.z};
+  std::memcpy(out, v, sizeof v);
+}
+uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+float u2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+// Appends `s` (and, first, everything it instances) to the flat arrays; returns its root node index.
+Flat::Placed place(Flat &f, const Scene &s) {
+  auto it = f.placed.find(&s);
+  if (it != f.placed.end()) return it->second;
+  const Bvh &b = s.bvh;
+  // Inner scenes first, so their roots are known when this scene's instance records are written.
+  std::vector<Flat::Placed> inner(b.prims.size(), Flat::Placed{CRT_INVALID_ID, 0});
+  for (size_t i = 0; i < b.prims.size(); i++)
+    if (b.prims[i].kind == PRIM_INSTANCE) inner[i] = place(f, *b.prims[i].scene);
+
+  const uint32_t node0 = uint32_t(f.nodes.size()), leaf0 = uint32_t(f.leaves.size());
+  const uint32_t pkt0 = uint32_t(f.packets.size()), idx0 = uint32_t(f.indices.size());
+  const uint32_t prim0 = uint32_t(f.prims.size());
+  for (WideNode n : b.wide) {
+    for (int l = 0; l < 4; l++) {
+      if (!(n.flags & (1u << l))) continue;
+      n.child[l] += (n.flags & (1u << (4 + l))) ? leaf0 : node0;
+    }
+    f.nodes.push_back(n);
+  }
+  for (Leaf l : b.leaves) {
+    l.pkt_first += pkt0;
+    l.idx_first += idx0;
+    f.leaves.push_back(l);
+  }
+  for (Tri4 p : b.packets) {
+    for (int l = 0; l < 4; l++)
+      if (p.active & (1u << l)) p.prim[l] += prim0;
+    f.packets.push_back(p);
+  }
+  for (uint32_t i : b.indices) f.indices.push_back(i + prim0);
+  for (size_t i = 0; i < b.prims.size(); i++) {
+    const Prim &p = b.prims[i];
+    DevPrim d{};
+    d.kind = p.kind;
+    d.geom_id = p.geom_id;
+    d.prim_id = p.prim_id;
+    d.mask = p.mask;
+    if (p.kind == PRIM_TRI) {
+      const float v[9] = {p.v0.x, p.v0.y, p.v0.z, p.v1.x, p.v1.y, p.v1.z, p.v2.x, p.v2.y, p.v2.z};
+      std::memcpy(d.d, v, sizeof v);
+      uint32_t slot = 0xFFFFFFFFu;
+      if (p.has_normals) {
+        slot = uint32_t(f.normals.size() / 9);
+        const float n[9] = {p.n0.x, p.n0.y, p.n0.z, p.n1.x, p.n1.y, p.n1.z, p.n2.x, p.n2.y, p.n2.z};
+        f.normals.insert(f.normals.end(), n, n + 9);
+      }
+      d.d[9] = u2f(slot);
+    } else if (p.kind == PRIM_SPHERE) {
+      d.d[0] = p.center.x; d.d[1] = p.center.y; d.d[2] = p.center.z; d.d[3] = p.radius;
+    } else {
+      DevInstance in{};
+      put_affine(in.w2l, p.w2l);
+      const float nm[9] = {p.normal_mat.x.x, p.normal_mat.x.y, p.normal_mat.x.z, p.normal_mat.y.x, p.normal_mat.y.y,
+                           p.normal_mat.y.z, p.normal_mat.z.x, p.normal_mat.z.y, p.normal_mat.z.z};
+      std::memcpy(in.nmat, nm, sizeof nm);
+      in.root = inner[i].root;
+      in.has_packets = inner[i].has_packets;
+      in.has_end = p.has_end ? 1u : 0u;
+      put_affine(in.l2w, p.l2w);
+      put_affine(in.l2w_end, p.has_end ? p.l2w_end : p.l2w);
+      d.d[0] = u2f(uint32_t(f.instances.size()));
+      f.instances.push_back(in);
+    }
+    f.prims.push_back(d);
+  }
+  Flat::Placed me{b.wide.empty() ? CRT_INVALID_ID : node0, b.packets.empty() ? 0u : 1u};
+  f.placed.emplace(&s, me);
+  return me;
+}
+}  // namespace
+
+int Scene::ensure_device() {
+  std::lock_guard<std::mutex> lock(dev_mu);
+  if (dev) return CRT_OK;
+  if (!device_ok()) return CRT_ERR_NO_DEVICE;
+  Flat f;
+  Flat::Placed me = place(f, *this);
+  auto img = std::make_unique<DeviceImage>();
+  const size_t sz[7] = {f.nodes.size() * sizeof(WideNode), f.leaves.size() * sizeof(Leaf),
+                        f.packets.size() * sizeof(Tri4),   f.indices.size() * sizeof(uint32_t),
+                        f.prims.size() * sizeof(DevPrim),  f.instances.size() * sizeof(DevInstance),
+                        f.normals.size() * sizeof(float)};
+  const void *src[7] = {f.nodes.data(), f.leaves.data(), f.packets.data(), f.indices.data(),
+                        f.prims.data(), f.instances.data(), f.normals.data()};
+  size_t off[7], total = 0;
+  for (int i = 0; i < 7; i++) {
+    off[i] = total;
+    total += (sz[i] + 255) & ~size_t(255);  // every array starts on a 256-byte boundary
+    img->bytes[i] = sz[i];
+  }
+  if (total == 0) total = 256;
+  if (hipMalloc(&img->blob, total) != hipSuccess) return CRT_ERR_NO_DEVICE;
+  for (int i = 0; i < 7; i++)
+    if (sz[i] && hipMemcpy(static_cast<char *>(img->blob) + off[i], src[i], sz[i], hipMemcpyHostToDevice) != hipSuccess)
+      return CRT_ERR_NO_DEVICE;
+  char *base = static_cast<char *>(img->blob);
+  img->view.nodes = reinterpret_cast<const WideNode *>(base + off[0]);
+  img->view.leaves = reinterpret_cast<const Leaf *>(base + off[1]);
+  img->view.packets = reinterpret_cast<const Tri4 *>(base + off[2]);
+  img->view.indices = reinterpret_cast<const uint32_t *>(base + off[3]);
+  img->view.prims = reinterpret_cast<const DevPrim *>(base + off[4]);
+  img->view.instances = reinterpret_cast<const DevInstance *>(base + off[5]);
+  img->view.normals = reinterpret_cast<const float *>(base + off[6]);
+  img->view.root = me.root;
+  img->view.has_packets = me.has_packets;
+  dev = std::move(img);
+  return CRT_OK;
+}
+
+}  // namespace crt

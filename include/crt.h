@@ -1,0 +1,236 @@
+/* crt.h — C ABI of the MI355X-native crust-rt backend (libcrt_amd.so).
+ *
+ * Drop-in boundary for crust-render's kernel seam: every entry point below is what a Rust FFI
+ * shim behind `crust_rt::{Geometry, SceneBuilder, Scene}` would bind. The
+ * reference interface each one replaces is cited as file:line under /root/reference/.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only; no C++/torch types. All functions are `extern "C"`.
+ *  - Geometry arrays are COPIED at attach time; the caller keeps ownership of its buffers
+ *    (the reference moves Vecs into the builder, scene.rs:158-166).
+ *  - Return value CRT_OK (0) or a negative CrtStatus. Nothing unwinds across the boundary. The
+ *    reference returns no errors on this path (misses are None/false); where it would panic
+ *    (set_geometry on an unknown id, scene.rs:197-201) this ABI returns CRT_ERR_BAD_ID.
+ *  - A miss is reported as geom_id == CRT_INVALID_ID (lib.rs:53).
+ *  - Device pointers: the *_n entry points take pointers to HBM-resident buffers and a HIP stream
+ *    handle (hipStream_t passed as void*; NULL = the default stream). The *1 entry points take host
+ *    pointers and synchronise.
+ *  - The library requires a gfx950 device. There is NO CPU fallback: without a usable HIP device
+ *    every query/render entry point returns CRT_ERR_NO_DEVICE.
+ */
+#ifndef CRT_H
+#define CRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRT_INVALID_ID 0xFFFFFFFFu /* lib.rs:53 INVALID_ID */
+#define CRT_MASK_CAMERA 1u         /* ray.rs:8  */
+#define CRT_MASK_SHADOW 2u         /* ray.rs:9  */
+#define CRT_MASK_INDIRECT 4u       /* ray.rs:10 */
+#define CRT_MASK_ALL 0xFFFFFFFFu   /* ray.rs:11 */
+
+typedef enum {
+  CRT_OK = 0,
+  CRT_ERR_BAD_ARG = -1,
+  CRT_ERR_BAD_ID = -2,     /* scene.rs:197-201 (panic in the reference) */
+  CRT_ERR_NO_DEVICE = -3,  /* no gfx950 HIP device / HIP call failed */
+  CRT_ERR_STACK = -4,      /* traversal stack capacity exceeded (never on trees the builder emits) */
+  CRT_ERR_UNSUPPORTED = -5 /* RoundCurves / CubicCurves (scene.rs:99-106): out of scope */
+} CrtStatus;
+
+/* crust_rt::Ray (ray.rs:18-23): origin/dir are glam Vec3A (16-byte, w unused), then time, mask. 48 bytes. */
+typedef struct CrtRay {
+  float origin[3]; float _pad0;
+  float dir[3];    float _pad1;
+  float time;
+  uint32_t mask;
+  uint32_t _pad2[2];
+} CrtRay;
+
+/* crust_rt::RayHit (scene.rs:134-142). 40 bytes. geom_id == CRT_INVALID_ID on a miss. */
+typedef struct CrtRayHit {
+  float t;
+  float normal[3];   /* ray-facing (scene.rs:356-359) */
+  uint32_t front_face;
+  float u, v;        /* u weights v1, v weights v2 (triangle.rs:84-86) */
+  uint32_t geom_id;
+  uint32_t prim_id;
+  uint32_t _pad;
+} CrtRayHit;
+
+/* bvh.rs:39-57 `traversal-stats` mirror; index 0 = top-level tree, 1 = inside an instance. */
+typedef struct CrtTravStats {
+  uint64_t queries[2], nodes[2], leaves[2], packets[2], prims[2];
+  uint64_t accepted_hits, instance_descents, rays;
+} CrtTravStats;
+
+typedef struct CrtBuilder CrtBuilder; /* crust_rt::SceneBuilder (scene.rs:147-149) */
+typedef struct CrtScene CrtScene;     /* crust_rt::Scene, ref-counted like Arc<Scene> (scene.rs:345-349) */
+
+/* ---- SceneBuilder (scene.rs:151-342) ---- */
+CrtBuilder *crt_builder_new(void);                                  /* SceneBuilder::new            scene.rs:152 */
+void crt_builder_free(CrtBuilder *b);                               /* drop without commit                       */
+int crt_reserve(CrtBuilder *b, size_t additional);                  /* SceneBuilder::reserve        scene.rs:174 */
+size_t crt_count(const CrtBuilder *b);                              /* SceneBuilder::count          scene.rs:179 */
+/* attach_masked(Geometry::TriangleMesh{vertices, indices, normals}, mask) -> geom_id   scene.rs:163, :88-94.
+ * verts: n_verts*3 floats; indices: n_tris*3 u32; normals: NULL or n_normals*3 floats. */
+int crt_attach_triangles(CrtBuilder *b, const float *verts, size_t n_verts, const uint32_t *indices, size_t n_tris,
+                         const float *normals, size_t n_normals, uint32_t mask, uint32_t *geom_id_out);
+/* attach_masked(Geometry::Sphere{center, radius}, mask)                               scene.rs:95-98 */
+int crt_attach_sphere(CrtBuilder *b, const float center[3], float radius, uint32_t mask, uint32_t *geom_id_out);
+/* attach_masked(Geometry::Instance{scene, transform, transform_end}, mask)            scene.rs:111-121.
+ * l2w / l2w_end: glam Affine3A as 12 floats (matrix3 columns x, y, z then translation); l2w_end may be
+ * NULL. The builder retains `scene`. */
+int crt_attach_instance(CrtBuilder *b, CrtScene *scene, const float l2w[12], const float *l2w_end, uint32_t mask,
+                        uint32_t *geom_id_out);
+/* attach_masked(SceneBuilder::empty_geometry(), mask)                                 scene.rs:205-211 */
+int crt_attach_empty(CrtBuilder *b, uint32_t mask, uint32_t *geom_id_out);
+/* set_geometry(id, ...) keeping the slot's mask                                       scene.rs:199-201 */
+int crt_set_triangles(CrtBuilder *b, uint32_t id, const float *verts, size_t n_verts, const uint32_t *indices,
+                      size_t n_tris, const float *normals, size_t n_normals);
+int crt_set_sphere(CrtBuilder *b, uint32_t id, const float center[3], float radius);
+int crt_set_instance(CrtBuilder *b, uint32_t id, CrtScene *scene, const float l2w[12], const float *l2w_end);
+/* commit(self) -> Scene: consumes the builder (scene.rs:226). Deterministic SBVH build + BVH4 collapse
+ * on the host (bvh.rs:300-327); the device image is created on first query. */
+CrtScene *crt_commit(CrtBuilder *b);
+
+/* ---- Scene (scene.rs:351-479) ---- */
+void crt_scene_retain(CrtScene *s);                                 /* Arc::clone */
+void crt_scene_release(CrtScene *s);                                /* drop(Arc)  */
+int crt_scene_bounds(const CrtScene *s, float out_min_max[6]);      /* Scene::bounds -> 1 if Some  scene.rs:375 */
+uint32_t crt_scene_geometry_count(const CrtScene *s);               /* scene.rs:380 */
+int crt_scene_has_motion(const CrtScene *s);                        /* scene.rs:395 */
+size_t crt_scene_primitive_count(const CrtScene *s);                /* scene.rs:400 */
+/* primitive_breakdown: triangles, spheres, curve_segments, cubic_curve_spans, instances   scene.rs:409 */
+int crt_scene_primitive_breakdown(const CrtScene *s, size_t out[5]);
+/* memory_footprint: prim_nodes, boxed_prims, bvh_nodes, leaves, packets, indices (device bytes) scene.rs:459 */
+int crt_scene_memory_footprint(CrtScene *s, size_t out[6]);
+/* Host copies of the committed tree of THIS scene (local indices), for build-parity checks:
+ * counts = nodes, leaves, packets, indices, prims. Pointers stay valid while the scene lives. */
+int crt_scene_tree(const CrtScene *s, size_t counts[5], const void **nodes128, const void **leaves16,
+                   const void **packets192, const uint32_t **indices);
+
+/* Scene::intersect(&ray, t_min, t_max) -> Option<RayHit>: 1 = hit, 0 = miss, <0 error      scene.rs:354 */
+int crt_intersect1(CrtScene *s, const CrtRay *ray, float t_min, float t_max, CrtRayHit *hit);
+/* Scene::occluded(&ray, t_min, t_max) -> bool: 1 / 0 / <0                                  scene.rs:370 */
+int crt_occluded1(CrtScene *s, const CrtRay *ray, float t_min, float t_max);
+/* Batched forms for the wavefront integrator: d_rays / d_hits / d_out are DEVICE pointers,
+ * n rays, launched on `stream` without synchronising. d_out: one u32 per ray (1 = occluded). */
+int crt_intersect_n(CrtScene *s, const CrtRay *d_rays, size_t n, float t_min, float t_max, CrtRayHit *d_hits,
+                    void *stream);
+int crt_occluded_n(CrtScene *s, const CrtRay *d_rays, size_t n, float t_min, float t_max, uint32_t *d_out,
+                   void *stream);
+/* Same launches with the traversal counters compiled in; counts are added into *host_stats after a
+ * stream sync. Take counts from these and timings from the plain forms (bvh.rs:31-38). */
+int crt_intersect_n_stats(CrtScene *s, const CrtRay *d_rays, size_t n, float t_min, float t_max, CrtRayHit *d_hits,
+                          void *stream, CrtTravStats *host_stats);
+int crt_occluded_n_stats(CrtScene *s, const CrtRay *d_rays, size_t n, float t_min, float t_max, uint32_t *d_out,
+                         void *stream, CrtTravStats *host_stats);
+
+/* ---- shading seam: the closed Material table (material.rs:26-116, rt_world.rs:111-122) ---- */
+enum { CRT_MAT_OPENPBR = 0, CRT_MAT_EMISSIVE = 1 };
+/* OpenPBR parameter block (openpbr.rs:66-121); for CRT_MAT_EMISSIVE only emission_color (the emitted
+ * radiance, emissive.rs:12-14) is read. */
+typedef struct CrtMaterial {
+  uint32_t kind;
+  uint32_t thin_walled;
+  float base_weight; float base_color[3]; float base_diffuse_roughness; float base_metalness;
+  float specular_weight; float specular_color[3]; float specular_roughness; float specular_ior;
+  float specular_roughness_anisotropy;
+  float transmission_weight; float transmission_color[3]; float transmission_depth; float transmission_scatter[3];
+  float transmission_scatter_anisotropy; float transmission_dispersion_scale; float transmission_dispersion_abbe_number;
+  float subsurface_weight; float subsurface_color[3]; float subsurface_radius; float subsurface_radius_scale[3];
+  float subsurface_scatter_anisotropy;
+  float fuzz_weight; float fuzz_color[3]; float fuzz_roughness;
+  float coat_weight; float coat_color[3]; float coat_roughness; float coat_roughness_anisotropy; float coat_ior;
+  float coat_darkening;
+  float thin_film_weight; float thin_film_thickness; float thin_film_ior;
+  float emission_luminance; float emission_color[3];
+  float geometry_opacity;
+} CrtMaterial;
+void crt_material_default(CrtMaterial *m);                          /* OpenPBR::default   openpbr.rs:130-173 */
+
+enum { CRT_LIGHT_SPHERE = 0, CRT_LIGHT_RECT = 1 };
+/* AreaLight{shape, material, geom_id} (light.rs:156-163) with SphereShape (:22-25) / RectShape (:52-57). */
+typedef struct CrtLight {
+  uint32_t kind; uint32_t geom_id;
+  float radiance[3];
+  float center[3]; float radius;
+  float origin[3]; float edge_u[3]; float edge_v[3]; float normal[3];
+} CrtLight;
+
+/* Camera (camera.rs:8-25), already in its derived form. */
+typedef struct CrtCamera {
+  float origin[3], lower_left[3], horizontal[3], vertical[3], u[3], v[3];
+  float lens_radius;
+} CrtCamera;
+/* Camera::new(lookfrom, lookat, vup, vfov_deg, aspect, aperture, focus_dist)   camera.rs:27-63 */
+void crt_camera_new(CrtCamera *c, const float lookfrom[3], const float lookat[3], const float vup[3], float vfov_deg,
+                    float aspect, float aperture, float focus_dist);
+
+enum { CRT_STRATEGY_POWER = 0, CRT_STRATEGY_BALANCE = 1, CRT_STRATEGY_LIGHT = 2, CRT_STRATEGY_BSDF = 3 }; /* tracer.rs:63-75 */
+enum { CRT_FILTER_BOX = 0, CRT_FILTER_TRIANGLE = 1 };                                                       /* filter.rs:27-41 */
+
+/* RenderSettings (tracer.rs:640-686) for the surface path. Adaptive stopping is not available on the
+ * wavefront path: variance_threshold must be 0 (the reference's own rule for comparable runs,
+ * scripts/check_images.sh:5-11). */
+typedef struct CrtRenderSettings {
+  uint32_t width, height;
+  uint32_t max_depth;
+  int32_t frame;
+  int32_t strategy;
+  int32_t filter_kind;
+  float filter_radius;
+  float variance_threshold;
+} CrtRenderSettings;
+
+/* RayStats (stats.rs:128-147). */
+typedef struct CrtRayStats {
+  uint64_t camera_rays, closest_hit, shadow_rays, vertices, rr_tested, rr_killed, ended_escaped, ended_depth;
+} CrtRayStats;
+
+typedef struct CrtRenderer CrtRenderer; /* Renderer{camera, world, lights, settings} (tracer.rs:137-148) */
+
+/* Renderer::new: binds the committed scene (retained), one material per geom_id (rt_world.rs:111-122),
+ * the light list (light.rs:392-395) and the camera. Pixel rows [row_begin, row_end) of the frame are this
+ * renderer's shard (pixel-tile sharding across ranks; pass 0, height for the whole frame). */
+CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, size_t n_materials,
+                              const CrtLight *lights, size_t n_lights, const CrtCamera *camera,
+                              const CrtRenderSettings *settings, uint32_t tile_rank, uint32_t tile_world);
+void crt_renderer_free(CrtRenderer *r);
+/* Number of pixels this renderer owns and their linear indices (j*width+i, buffer order) in sample order. */
+size_t crt_renderer_pixel_count(const CrtRenderer *r);
+int crt_renderer_pixel_indices(const CrtRenderer *r, uint32_t *out);
+/* Traces samples [sample_begin, sample_begin + sample_count) of every owned pixel as one wavefront batch
+ * on `stream` and adds them, in sample order, into the renderer's device-resident film sums
+ * (render_pixel's `sum += color`, tracer.rs:599). Does not synchronise. */
+int crt_render_samples(CrtRenderer *r, uint32_t sample_begin, uint32_t sample_count, void *stream);
+/* Film: pixel = sum / weight_sum (tracer.rs:630-634) for the owned pixels, in pixel_indices order,
+ * written to a DEVICE buffer of pixel_count*3 floats (d_rgb), or a HOST buffer via crt_film_read. */
+int crt_film_resolve(CrtRenderer *r, float *d_rgb, void *stream);
+int crt_film_read(CrtRenderer *r, float *host_rgb);
+int crt_film_clear(CrtRenderer *r, void *stream);
+/* Counters since the last clear (syncs the stream the batches ran on). */
+int crt_render_stats(CrtRenderer *r, CrtRayStats *out);
+/* Live HIP-event timing of the kernels launched by crt_render_samples since the last reset, by class:
+ * 0 = extend (closest-hit traversal), 1 = shade, 2 = shadow (occlusion traversal), 3 = other.
+ * out_ms[k] = summed duration, out_launches[k] = launches. Enabled by crt_renderer_profile(r, 1). */
+int crt_renderer_profile(CrtRenderer *r, int enable);
+int crt_renderer_profile_read(CrtRenderer *r, double out_ms[4], uint64_t out_launches[4]);
+/* Traversal counters of the extend+shadow kernels for one batch (separate stats build of the kernels). */
+int crt_render_samples_stats(CrtRenderer *r, uint32_t sample_begin, uint32_t sample_count, void *stream,
+                             CrtTravStats *host_stats);
+
+/* Library / device info. */
+const char *crt_version(void);
+int crt_device_info(char *name_out, size_t name_cap, int *cu_count, size_t *hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRT_H */

@@ -1,0 +1,49 @@
+"""The product's host builder (C++, crust-render_amd/csrc/bvh_build.cpp) must emit the same tree as the
+oracle's independent restatement (plain C, oracle/ora_rt.c): node bounds, child links, flags, leaf ranges,
+packet lanes and index order, word for word. Runs on CPU (the builder is host code)."""
+import numpy as np
+import pytest
+
+import ora
+import scenes
+
+
+@pytest.mark.parametrize("name", list(scenes.ALL))
+def test_tree_matches_oracle(crt, name):
+    make, _ = scenes.ALL[name]
+    a = make(ora)
+    b = make(crt)
+    on, ol, op, oi = a.arrays()
+    pn, pl, pp, pi, counts = b.tree()
+    assert counts == a.counts()
+    assert np.array_equal(on[:, :29], pn[:, :29])  # bounds, children, flags (pad words excluded)
+    assert np.array_equal(ol, pl)
+    assert np.array_equal(op[:, :47], pp[:, :47])  # word 47 is the device-only normal_ok nibble
+    assert np.array_equal(oi, pi)
+    ob, pb = a.bounds(), b.bounds()
+    assert (ob is None and pb is None) or np.array_equal(ob.view(np.uint32), pb.view(np.uint32))
+    assert a.primitive_count() == b.primitive_count() and a.geometry_count() == b.geometry_count()
+    assert a.has_motion() == b.has_motion()
+
+
+def test_empty_and_reserved_slots(crt):
+    b = crt.SceneBuilder()
+    s = b.commit()
+    assert s.bounds() is None and s.primitive_count() == 0
+    b = crt.SceneBuilder()
+    a = b.attach_sphere((-5, 0, 0), 1.0)
+    ph = b.attach_empty()
+    c = b.attach_sphere((5, 0, 0), 1.0)
+    assert (a, ph, c) == (0, 1, 2) and b.count() == 3
+    s = b.commit()
+    assert s.geometry_count() == 3 and s.primitive_count() == 2  # scene.rs:499-516
+    b = crt.SceneBuilder()
+    with pytest.raises(crt.CrtError) as e:
+        b.set_sphere(7, (0, 0, 0), 1.0)  # scene.rs:197-201: the reference panics
+    assert e.value.code == -2
+
+
+def test_out_of_range_indices_are_skipped(crt):
+    b = crt.SceneBuilder()
+    b.attach_triangles([(0, 0, 0), (1, 0, 0), (0, 1, 0)], [(0, 1, 2), (0, 1, 9)])  # scene.rs:251-253
+    assert b.commit().primitive_count() == 1
