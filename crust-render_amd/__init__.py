@@ -34,7 +34,12 @@ _ERRORS = {-1: "CRT_ERR_BAD_ARG", -2: "CRT_ERR_BAD_ID", -3: "CRT_ERR_NO_DEVICE",
 
 class CrtError(RuntimeError):
     def __init__(self, code, what=""):
-        super().__init__(f"{what}: {_ERRORS.get(code, code)}")
+        detail = ""
+        try:
+            detail = _lib.crt_last_error().decode() if _lib is not None else ""
+        except Exception:
+            pass
+        super().__init__(f"{what}: {_ERRORS.get(code, code)}" + (f" [{detail}]" if detail else ""))
         self.code = code
 
 
@@ -145,7 +150,7 @@ ABI_SYMBOLS = [
     "crt_occluded_n_stats", "crt_material_default", "crt_camera_new", "crt_renderer_new", "crt_renderer_free",
     "crt_renderer_pixel_count", "crt_renderer_pixel_indices", "crt_render_samples", "crt_film_resolve",
     "crt_film_read", "crt_film_clear", "crt_render_stats", "crt_renderer_profile", "crt_renderer_profile_read",
-    "crt_render_samples_stats", "crt_version", "crt_device_info",
+    "crt_render_samples_stats", "crt_version", "crt_last_error", "crt_device_info",
 ]
 
 _lib = None
@@ -159,9 +164,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc, gfx950). "
                            "crust-render_amd has no CPU fallback.")
+    # torch owns device memory and streams for this package; importing it first makes the process use ONE HIP
+    # runtime (libcrt_amd.so's libamdhip64.so.7 dependency then binds to the copy torch already loaded).
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     fp, up, vp = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_void_p
     L.crt_version.restype = C.c_char_p
+    L.crt_last_error.restype = C.c_char_p
     L.crt_device_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
     L.crt_builder_new.restype = vp
     L.crt_builder_free.argtypes = [vp]

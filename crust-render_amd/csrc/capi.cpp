@@ -9,6 +9,7 @@
 
 namespace crt {
 int traversal_error_check(void *stream);
+const char *last_error_text();
 }
 
 using namespace crt;
@@ -47,6 +48,7 @@ void fill_instance(Geom &g, CrtScene *scene, const float l2w[12], const float *l
 extern "C" {
 
 const char *crt_version(void) { return "crt_amd 0.1 (gfx950)"; }
+const char *crt_last_error(void) { return crt::last_error_text(); }
 
 int crt_device_info(char *name_out, size_t name_cap, int *cu_count, size_t *hbm_bytes) {
   if (!device_ok()) return CRT_ERR_NO_DEVICE;

@@ -185,6 +185,10 @@ int launch_occluded_n(const DevScene &s, const CrtRay *d_rays, size_t n, float t
                       void *stream, CrtTravStats *d_stats);
 int device_ok();
 
+// Records the failing HIP call for crt_last_error() and returns false.
+bool hip_failed(int /*hipError_t*/ err, const char *what, const char *file, int line);
+#define CRT_HIP_OK(call) (!::crt::hip_failed((int)(call), #call, __FILE__, __LINE__))
+
 }  // namespace crt
 
 struct CrtScene { std::shared_ptr<crt::Scene> p; std::atomic<int> refs{1}; };

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(kBlock) void occluded_n_kernel(DevScene S, const Cr
 uint32_t *device_err_word() {
   static uint32_t *p = [] {
     uint32_t *q = nullptr;
-    if (hipMalloc(&q, sizeof(uint32_t)) != hipSuccess) return (uint32_t *)nullptr;
+    if (!CRT_HIP_OK(hipMalloc(&q, sizeof(uint32_t)))) return (uint32_t *)nullptr;
     (void)hipMemset(q, 0, sizeof(uint32_t));
     return q;
   }();
@@ -102,7 +102,7 @@ int grid_for(size_t n) {
     hipDeviceProp_t prop;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    if (!CRT_HIP_OK(hipGetDeviceProperties(&prop, dev))) return 256;
     return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }();
   size_t need = (n + kBlock - 1) / kBlock;
@@ -137,7 +137,7 @@ int launch_intersect_n(const DevScene &s, const CrtRay *d_rays, size_t n, float 
   else
     hipLaunchKernelGGL(intersect_n_kernel<false>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, s, d_rays, n, t_min,
                        t_max, d_hits, e, d_stats);
-  return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_NO_DEVICE;
+  return CRT_HIP_OK(hipGetLastError()) ? CRT_OK : CRT_ERR_NO_DEVICE;
 }
 
 int launch_occluded_n(const DevScene &s, const CrtRay *d_rays, size_t n, float t_min, float t_max, uint32_t *d_out,
@@ -152,7 +152,7 @@ int launch_occluded_n(const DevScene &s, const CrtRay *d_rays, size_t n, float t
   else
     hipLaunchKernelGGL(occluded_n_kernel<false>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, s, d_rays, n, t_min,
                        t_max, d_out, e, d_stats);
-  return hipGetLastError() == hipSuccess ? CRT_OK : CRT_ERR_NO_DEVICE;
+  return CRT_HIP_OK(hipGetLastError()) ? CRT_OK : CRT_ERR_NO_DEVICE;
 }
 
 }  // namespace crt

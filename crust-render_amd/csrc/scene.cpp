@@ -7,6 +7,7 @@
 // another root node in the same arrays.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstring>
 #include <unordered_map>
 
@@ -137,10 +138,19 @@ DeviceImage::~DeviceImage() {
   if (blob) (void)hipFree(blob);
 }
 
+static thread_local char g_last_error[512] = "";
+const char *last_error_text() { return g_last_error; }
+bool hip_failed(int err, const char *what, const char *file, int line) {
+  if (err == (int)hipSuccess) return false;
+  std::snprintf(g_last_error, sizeof g_last_error, "%s -> %s (%d) at %s:%d", what, hipGetErrorString((hipError_t)err), err,
+                file, line);
+  return true;
+}
+
 int device_ok() {
   static int ok = [] {
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+    if (!CRT_HIP_OK(hipGetDeviceCount(&n)) || n <= 0) return 0;
     return 1;
   }();
   return ok;
@@ -258,9 +268,9 @@ int Scene::ensure_device() {
     img->bytes[i] = sz[i];
   }
   if (total == 0) total = 256;
-  if (hipMalloc(&img->blob, total) != hipSuccess) return CRT_ERR_NO_DEVICE;
+  if (!CRT_HIP_OK(hipMalloc(&img->blob, total))) return CRT_ERR_NO_DEVICE;
   for (int i = 0; i < 7; i++)
-    if (sz[i] && hipMemcpy(static_cast<char *>(img->blob) + off[i], src[i], sz[i], hipMemcpyHostToDevice) != hipSuccess)
+    if (sz[i] && !CRT_HIP_OK(hipMemcpy(static_cast<char *>(img->blob) + off[i], src[i], sz[i], hipMemcpyHostToDevice)))
       return CRT_ERR_NO_DEVICE;
   char *base = static_cast<char *>(img->blob);
   img->view.nodes = reinterpret_cast<const WideNode *>(base + off[0]);

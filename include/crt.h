@@ -226,8 +226,9 @@ int crt_renderer_profile_read(CrtRenderer *r, double out_ms[4], uint64_t out_lau
 int crt_render_samples_stats(CrtRenderer *r, uint32_t sample_begin, uint32_t sample_count, void *stream,
                              CrtTravStats *host_stats);
 
-/* Library / device info. */
+/* Library / device info. crt_last_error: text of the last failing HIP call on this thread ("" if none). */
 const char *crt_version(void);
+const char *crt_last_error(void);
 int crt_device_info(char *name_out, size_t name_cap, int *cu_count, size_t *hbm_bytes);
 
 #ifdef __cplusplus
