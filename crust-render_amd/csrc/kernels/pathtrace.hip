@@ -1,0 +1,747 @@
+// Wavefront path tracer for gfx950: the surface arm of crust-core's integrator as data-parallel stages.
+//
+// What it computes: crates/crust-core/src/tracer.rs:515-636 (render_pixel), :1086-1558 (trace_path, surface
+// arm), :930-953 (bounce_emission_weight), :1016-1035 (shadow test), :85-104 (MIS weights), :1478-1490
+// (Russian roulette), :1327-1340 (sky), rt_world.rs:207-237, light.rs:421-440 — with the backward gather
+// (tracer.rs:1537-1557) restated as the algebraically identical forward accumulation
+//     L += beta * w * emitted      (bounce-hit emission, weighted for the previous vertex)
+//     L += beta * emit_here        (primary vertex only)
+//     L += beta * nee              (after the shadow ray)
+//     beta *= value * cos / pdf    (then / p_survive under roulette)
+// in exactly that order, which is the order the CPU oracle's forward mode uses (oracle/ora_pt.c), so the
+// two agree bit for bit.
+//
+// Stages per bounce, each a persistent grid-stride launch over a device-resident queue (no host sync):
+//   generate : camera samples -> path state (SoA), one slot per (pixel, sample)
+//   extend   : closest-hit traversal of the live paths              -> hit records
+//   shade    : emission + MIS, light sampling -> shadow queue, BSDF sampling, roulette;
+//              survivors are compacted into the other state buffer with a wave ballot + prefix popcount
+//              and ONE atomic per wave; finished paths write their radiance to the film staging plane
+//   shadow   : any-hit traversal of the shadow queue; unoccluded requests add their contribution
+//   resolve  : staging planes are folded into the film in sample order (sum += color, tracer.rs:599)
+// Path state is struct-of-arrays so every stage's loads and stores are unit-stride across a wave.
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "shade.hip.h"
+#include "traverse.hip.h"
+
+namespace crt {
+
+using namespace dev;
+
+namespace {
+
+enum { K_CAMERA = 0, K_PATH = 1, K_TIME = 2 };                 // tracer.rs:20-22 (off root)
+enum { K_NEE = 0, K_BSDF = 2, K_RR = 5 };                      // tracer.rs:23-28 (off vertex)
+constexpr int kRrStartBounce = 3;                              // tracer.rs:46
+constexpr float kRrMinProb = 0.05f;                            // tracer.rs:47
+constexpr uint32_t kFilmTarget = 0x80000000u;
+constexpr uint32_t kPrevValid = 1u << 16, kPrevDelta = 1u << 17;
+
+// One set of path-state planes (struct of arrays, capacity `cap` each).
+struct PathSoA {
+  float *ox, *oy, *oz, *dx, *dy, *dz, *time;
+  float *bx, *by, *bz;      // beta: the running throughput (tracer.rs:1114)
+  float *lx, *ly, *lz;      // L: radiance gathered so far
+  float *px, *py, *pz;      // previous vertex position (PrevBounce::rec.p, tracer.rs:899-906)
+  float *ppdf;              // previous bounce pdf
+  uint32_t *pattern;        // sampler state of the path's K_PATH domain
+  uint32_t *pix;            // index into the owned-pixel list
+  uint32_t *meta;           // n_rec (low 16) | remaining depth (high 16)
+  uint32_t *aux;            // sample-in-batch (low 16) | kPrevValid | kPrevDelta
+};
+struct HitSoA { float *t, *nx, *ny, *nz; uint32_t *geom; };  // geom: id | front_face << 31; ~0 = miss
+struct ShadowSoA { float *ox, *oy, *oz, *dx, *dy, *dz, *tmax, *time, *cx, *cy, *cz; uint32_t *target; };
+
+struct Counters {
+  uint32_t count[2];  // live paths in state buffer 0 / 1
+  uint32_t n_shadow;
+  uint32_t err;
+  unsigned long long stats[8];  // RayStats (stats.rs:128-147) in declaration order
+};
+
+struct Params {
+  DevScene scene;
+  uint32_t sample_begin;
+  const CrtMaterial *materials;
+  const CrtLight *lights;
+  uint32_t n_lights;
+  CrtCamera camera;
+  uint32_t width, height, max_depth;
+  int32_t frame, strategy, filter_kind;
+  float filter_radius;
+  uint32_t has_motion;
+  const uint32_t *pixel_index;  // owned pixels: j * width + i
+  uint32_t n_pix;
+};
+
+__device__ __forceinline__ float light_weight(int s, float light_pdf, float bounce_pdf) {  // tracer.rs:85-92
+  switch (s) {
+    case CRT_STRATEGY_POWER: return power_heuristic(light_pdf, bounce_pdf);
+    case CRT_STRATEGY_BALANCE: return balance_heuristic(light_pdf, bounce_pdf);
+    case CRT_STRATEGY_LIGHT: return 1.0f;
+    default: return 0.0f;
+  }
+}
+__device__ __forceinline__ float bounce_weight(int s, float bounce_pdf, float light_pdf) {  // tracer.rs:97-104
+  switch (s) {
+    case CRT_STRATEGY_POWER: return power_heuristic(bounce_pdf, light_pdf);
+    case CRT_STRATEGY_BALANCE: return balance_heuristic(bounce_pdf, light_pdf);
+    case CRT_STRATEGY_LIGHT: return 0.0f;
+    default: return 1.0f;
+  }
+}
+
+// Wave-aggregated append: every lane with `want` gets a unique slot; one atomic per wave.
+__device__ __forceinline__ uint32_t wave_append(bool want, uint32_t *counter) {
+  const unsigned long long mask = __ballot(want);
+  if (mask == 0) return 0;
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll((long long)mask) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+  base = __shfl(base, leader, 64);
+  return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+__device__ __forceinline__ void add_stat(unsigned long long *slot, uint32_t v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(slot, (unsigned long long)v);
+}
+
+// ---- generate: PathSampler::new(...).new_domain(tile), camera sample, camera ray (tracer.rs:559-585) ----
+__global__ __launch_bounds__(kBlock) void k_generate(Params P, PathSoA S, Counters *C, uint32_t sample_begin,
+                                                     uint32_t n_samples) {
+  const size_t total = (size_t)P.n_pix * n_samples;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+    const uint32_t pix = (uint32_t)(i % P.n_pix), sl = (uint32_t)(i / P.n_pix);
+    const uint32_t lin = P.pixel_index[pix];
+    const uint32_t px = lin % P.width, py = lin / P.width;
+    const int tile = (int)(px >> 8) + (int)(py >> 8) * 4096;  // tracer.rs:543
+    const Sampler root = new_domain(sampler_new((int)px, (int)py, P.frame, (int)(sample_begin + sl)), tile);
+    float cam[4];
+    draw_sample4(new_domain(root, K_CAMERA), cam);
+    const float fx = filter_offset(P.filter_kind, P.filter_radius, cam[0]);
+    const float fy = filter_offset(P.filter_kind, P.filter_radius, cam[1]);
+    const float u = ((float)px + fx) / (float)P.width;
+    const float v = ((float)py + fy) / (float)P.height;
+    float time = 0.0f;
+    if (P.has_motion) {  // tracer.rs:579-583
+      float t4[4];
+      draw_sample4(new_domain(root, K_TIME), t4);
+      time = t4[0];
+    }
+    V3 o, d;
+    camera_get_ray(P.camera, u, v, cam[2], cam[3], o, d);
+    S.ox[i] = o.x; S.oy[i] = o.y; S.oz[i] = o.z; S.dx[i] = d.x; S.dy[i] = d.y; S.dz[i] = d.z; S.time[i] = time;
+    S.bx[i] = 1.0f; S.by[i] = 1.0f; S.bz[i] = 1.0f;
+    S.lx[i] = 0.0f; S.ly[i] = 0.0f; S.lz[i] = 0.0f;
+    S.px[i] = 0.0f; S.py[i] = 0.0f; S.pz[i] = 0.0f; S.ppdf[i] = 0.0f;
+    S.pattern[i] = new_domain(root, K_PATH).pattern;  // tracer.rs:1101
+    S.pix[i] = pix;
+    S.meta[i] = (P.max_depth & 0xffffu) << 16;
+    S.aux[i] = sl;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    C->count[0] = (uint32_t)total;
+    C->count[1] = 0;
+    C->n_shadow = 0;
+    atomicAdd(&C->stats[0], (unsigned long long)total);  // camera_rays (tracer.rs:585)
+  }
+}
+
+// ---- extend: World::intersect (rt_world.rs:207-232) for every live path ----
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_extend(Params P, PathSoA S, HitSoA H, Counters *C, int cur,
+                                                   CrtTravStats *tstats) {
+  __shared__ uint32_t stack[kStackLds * kBlock];
+  const uint32_t n = C->count[cur];
+  LaneStats st = {};
+  uint32_t err = 0, done = 0;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float ox = S.ox[i], oy = S.oy[i], oz = S.oz[i], dx = S.dx[i], dy = S.dy[i], dz = S.dz[i];
+    const uint32_t n_rec = S.meta[i] & 0xffffu;
+    const uint32_t mask = n_rec == 0 ? CRT_MASK_CAMERA : CRT_MASK_INDIRECT;  // camera.rs:83, tracer.rs:1516-1519
+    Hit h;
+    const bool hit = traverse<false, STATS>(P.scene, ox, oy, oz, dx, dy, dz, S.time[i], mask, 0.001f, CRT_INF, h,
+                                            &stack[threadIdx.x], err, st);
+    if (hit) {
+      const bool front = dot3(dx, dy, dz, h.nx, h.ny, h.nz) < 0.0f;  // scene.rs:356-359
+      H.t[i] = h.t;
+      H.nx[i] = front ? h.nx : -h.nx;
+      H.ny[i] = front ? h.ny : -h.ny;
+      H.nz[i] = front ? h.nz : -h.nz;
+      H.geom[i] = h.geom | (front ? 0x80000000u : 0u);
+    } else {
+      H.geom[i] = kInvalid;
+    }
+    done++;
+  }
+  if (err) atomicOr(&C->err, err);
+  if (STATS) {
+    auto wave_sum = [](uint32_t v) { for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64); return v; };
+    const bool lead = (threadIdx.x & 63) == 0;
+    for (int k = 0; k < 2; k++) {
+      const uint32_t a = wave_sum(st.queries[k]), b = wave_sum(st.nodes[k]), c = wave_sum(st.leaves[k]);
+      const uint32_t d = wave_sum(st.packets[k]), e = wave_sum(st.prims[k]);
+      if (lead) {
+        atomicAdd((unsigned long long *)&tstats->queries[k], (unsigned long long)a);
+        atomicAdd((unsigned long long *)&tstats->nodes[k], (unsigned long long)b);
+        atomicAdd((unsigned long long *)&tstats->leaves[k], (unsigned long long)c);
+        atomicAdd((unsigned long long *)&tstats->packets[k], (unsigned long long)d);
+        atomicAdd((unsigned long long *)&tstats->prims[k], (unsigned long long)e);
+      }
+    }
+    const uint32_t a = wave_sum(st.accepted), b = wave_sum(st.descents), c = wave_sum(done);
+    if (lead) {
+      atomicAdd((unsigned long long *)&tstats->accepted_hits, (unsigned long long)a);
+      atomicAdd((unsigned long long *)&tstats->instance_descents, (unsigned long long)b);
+      atomicAdd((unsigned long long *)&tstats->rays, (unsigned long long)c);
+    }
+  }
+}
+
+// ---- shade: one iteration of trace_path's loop body for every live path (tracer.rs:1118-1530) ----
+__global__ __launch_bounds__(kBlock) void k_shade(Params P, PathSoA S, PathSoA N, HitSoA H, ShadowSoA Q, Counters *C,
+                                                  int cur, float *staging, uint32_t staging_plane) {
+  const uint32_t n = C->count[cur];
+  uint32_t s_closest = 0, s_shadow = 0, s_vertices = 0, s_rr_t = 0, s_rr_k = 0, s_esc = 0, s_depth = 0;
+  const uint32_t stride = gridDim.x * kBlock;
+  const uint32_t rounds = (n + stride - 1) / stride;
+  for (uint32_t round = 0; round < rounds; round++) {
+    const uint32_t i = round * stride + blockIdx.x * kBlock + threadIdx.x;
+    const bool active = i < n;
+    bool alive = false, want_shadow = false;
+    V3 L = splat(0.0f), beta = splat(1.0f);
+    V3 n_o = splat(0.0f), n_d = splat(0.0f), sh_d = splat(0.0f), sh_c = splat(0.0f), hit_p = splat(0.0f);
+    float n_ppdf = 0.0f, sh_tmax = 0.0f, time = 0.0f;
+    uint32_t meta = 0, aux = 0, pix = 0, pattern = 0;
+    bool n_delta = false;
+    if (active) {
+      const V3 ro = v3(S.ox[i], S.oy[i], S.oz[i]), rd = v3(S.dx[i], S.dy[i], S.dz[i]);
+      time = S.time[i];
+      beta = v3(S.bx[i], S.by[i], S.bz[i]);
+      L = v3(S.lx[i], S.ly[i], S.lz[i]);
+      meta = S.meta[i]; aux = S.aux[i]; pix = S.pix[i]; pattern = S.pattern[i];
+      const uint32_t n_rec = meta & 0xffffu;
+      const int remaining = (int)(meta >> 16);
+      const bool prev_valid = (aux & kPrevValid) != 0, prev_delta = (aux & kPrevDelta) != 0;
+      const uint32_t hg = H.geom[i];
+      const bool has_hit = hg != kInvalid;
+      const uint32_t geom = hg & 0x7fffffffu;
+      HitRec rec;
+      rec.front_face = ((hg >> 31) & 1u) != 0;
+      rec.t = 0.0f; rec.normal = splat(0.0f); rec.p = splat(0.0f);
+      if (has_hit) {
+        rec.t = H.t[i];
+        rec.normal = v3(H.nx[i], H.ny[i], H.nz[i]);
+        rec.p = ro + rd * rec.t;  // ray.at(t), rt_world.rs:221
+      }
+      hit_p = rec.p;
+
+      // bounce_emission_weight (tracer.rs:930-953). A previous bounce exists only where scatter returned a
+      // sample, i.e. where eval is available, so the "eval is None" arm reduces to the delta flag.
+      auto emission_weight = [&]() -> float {
+        if (prev_delta) return 1.0f;
+        for (uint32_t k = 0; k < P.n_lights; k++) {  // LightList::find_by_geom, light.rs:436-440
+          if (P.lights[k].geom_id == geom) {
+            const V3 from = v3(S.px[i], S.py[i], S.pz[i]);
+            const float light_pdf = rmax(solid_angle_pdf(P.lights[k], from, rec.p) / (float)P.n_lights, 1e-6f);
+            return bounce_weight(P.strategy, S.ppdf[i], light_pdf);
+          }
+        }
+        return 1.0f;
+      };
+
+      if (remaining <= 0) {  // tracer.rs:1123-1149: depth exhausted, last-vertex emission only
+        s_depth++;
+        if (prev_valid) {
+          s_closest++;
+          if (has_hit) {
+            const CrtMaterial &mat = P.materials[geom];
+            const float cos_o = fabs_(dot(normalize(rd), rec.normal));
+            const V3 emitted = mat_emitted_directional(mat, cos_o);
+            if (len2(emitted) > 0.0f) L = L + beta * (emitted * emission_weight());
+          }
+        }
+      } else {
+        s_closest++;
+        if (!has_hit) {  // tracer.rs:1321-1342: background = sky gradient (no light at infinity in scope)
+          s_esc++;
+          const V3 unit_direction = normalize(rd);
+          const float t = 0.5f * (unit_direction.y + 1.0f);
+          const V3 background = splat(0.0f) + (v3(1.0f, 1.0f, 1.0f) * (1.0f - t) + v3(0.5f, 0.7f, 1.0f) * t);
+          L = L + beta * background;
+        } else {
+          const CrtMaterial &mat = P.materials[geom];
+          const V3 atten = splat(1.0f);  // no carried medium, no volume regions
+          const float cos_o = fabs_(dot(normalize(rd), rec.normal));
+          const V3 emitted = mat_emitted_directional(mat, cos_o);
+          V3 emit_here = splat(0.0f);
+          if (prev_valid) {  // tracer.rs:1372-1381
+            if (len2(emitted) > 0.0f) L = L + beta * ((atten * emitted) * emission_weight());
+          } else {
+            emit_here = emitted;
+          }
+          const Sampler vdom = new_domain(Sampler{pattern, P.sample_begin + (aux & 0xffffu)}, (int)n_rec);  // :1121
+
+          // === 1. direct lighting by light sampling (tracer.rs:1394-1445) ===
+          if (P.strategy != CRT_STRATEGY_BSDF && P.n_lights > 0) {
+            float nee_s[4];
+            draw_sample4(new_domain(vdom, K_NEE), nee_s);
+            uint32_t li = (uint32_t)(nee_s[0] * (float)P.n_lights);  // LightList::pick, light.rs:421-429
+            if (li > P.n_lights - 1) li = P.n_lights - 1;
+            const CrtLight &light = P.lights[li];
+            LightSample ls;
+            if (light_sample_li(light, rec.p, nee_s[1], nee_s[2], ls)) {
+              s_shadow++;  // the reference traces the shadow ray before it evaluates the BSDF (tracer.rs:1412-1425)
+              want_shadow = true;
+              sh_d = ls.direction;
+              sh_tmax = ls.distance - 0.001f;
+              const float cosine = fabs_(dot(rec.normal, ls.direction));
+              const float light_pdf = rmax(ls.pdf / (float)P.n_lights, 1e-6f);
+              V3 brdf_value; float brdf_pdf;
+              V3 nee = splat(0.0f);
+              if (mat_eval(mat, rd, rec, ls.direction, brdf_value, brdf_pdf)) {
+                const float weight = light_weight(P.strategy, light_pdf, brdf_pdf);
+                V3 c = (ls.radiance * brdf_value) * cosine;
+                c = c * splat(1.0f);  // shadow_tr == ONE when unoccluded
+                nee = nee + (c * weight) / light_pdf;
+              }
+              sh_c = beta * nee;  // added to L by the shadow stage iff the segment is unoccluded
+            }
+          }
+          L = L + beta * emit_here;
+
+          // === 2. indirect lighting by BSDF sampling (tracer.rs:1459-1523) ===
+          Scatter sample;
+          if (mat_scatter(mat, rd, rec, new_domain(vdom, K_BSDF), sample)) {
+            const V3 dir = normalize(sample.dir);
+            const float cosine = sample.delta ? 1.0f : fabs_(dot(rec.normal, dir));
+            const V3 factor = (sample.value * cosine) / sample.pdf;
+            beta = beta * (atten * factor);
+            bool survived = true;
+            if (n_rec >= (uint32_t)kRrStartBounce) {
+              s_rr_t++;
+              const float p_survive = rclamp(max_elem(beta), kRrMinProb, 1.0f);
+              if (p_survive < 1.0f) {
+                if (draw_rnd1(new_domain(vdom, K_RR)) >= p_survive) {
+                  survived = false;
+                  s_rr_k++;
+                } else {
+                  beta = beta / p_survive;
+                }
+              }
+            }
+            if (survived) {
+              alive = true;
+              n_o = sample.origin; n_d = sample.dir; n_ppdf = sample.pdf; n_delta = sample.delta;
+            }
+          }
+          s_vertices++;
+        }
+      }
+    }
+
+    // ---- wave-level compaction: survivors go to the other state buffer, finished paths to the film ----
+    const uint32_t j = wave_append(alive, &C->count[1 - cur]);
+    const uint32_t sl = aux & 0xffffu;
+    const uint32_t film_idx = sl * P.n_pix + pix;
+    if (alive) {
+      N.ox[j] = n_o.x; N.oy[j] = n_o.y; N.oz[j] = n_o.z; N.dx[j] = n_d.x; N.dy[j] = n_d.y; N.dz[j] = n_d.z;
+      N.time[j] = time;
+      N.bx[j] = beta.x; N.by[j] = beta.y; N.bz[j] = beta.z;
+      N.lx[j] = L.x; N.ly[j] = L.y; N.lz[j] = L.z;
+      N.px[j] = hit_p.x; N.py[j] = hit_p.y; N.pz[j] = hit_p.z; N.ppdf[j] = n_ppdf;
+      N.pattern[j] = pattern; N.pix[j] = pix;
+      N.meta[j] = ((meta & 0xffffu) + 1u) | (((meta >> 16) - 1u) << 16);
+      N.aux[j] = sl | kPrevValid | (n_delta ? kPrevDelta : 0u);
+    } else if (active) {
+      staging[film_idx] = L.x;
+      staging[(size_t)staging_plane + film_idx] = L.y;
+      staging[2 * (size_t)staging_plane + film_idx] = L.z;
+    }
+    const uint32_t q = wave_append(want_shadow, &C->n_shadow);
+    if (want_shadow) {
+      Q.ox[q] = hit_p.x; Q.oy[q] = hit_p.y; Q.oz[q] = hit_p.z; Q.dx[q] = sh_d.x; Q.dy[q] = sh_d.y; Q.dz[q] = sh_d.z;
+      Q.tmax[q] = sh_tmax; Q.time[q] = time;
+      Q.cx[q] = sh_c.x; Q.cy[q] = sh_c.y; Q.cz[q] = sh_c.z;
+      Q.target[q] = alive ? j : (kFilmTarget | film_idx);
+    }
+  }
+  add_stat(&C->stats[1], s_closest); add_stat(&C->stats[2], s_shadow); add_stat(&C->stats[3], s_vertices);
+  add_stat(&C->stats[4], s_rr_t); add_stat(&C->stats[5], s_rr_k); add_stat(&C->stats[6], s_esc);
+  add_stat(&C->stats[7], s_depth);
+}
+
+// ---- shadow: World::occluded (rt_world.rs:235-237) for the queue; unoccluded requests pay out ----
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_shadow(Params P, PathSoA N, ShadowSoA Q, Counters *C, float *staging,
+                                                   uint32_t staging_plane, CrtTravStats *tstats) {
+  __shared__ uint32_t stack[kStackLds * kBlock];
+  const uint32_t n = C->n_shadow;
+  LaneStats st = {};
+  uint32_t err = 0, done = 0;
+  for (uint32_t q = blockIdx.x * kBlock + threadIdx.x; q < n; q += gridDim.x * kBlock) {
+    Hit h;
+    const bool occ = traverse<true, STATS>(P.scene, Q.ox[q], Q.oy[q], Q.oz[q], Q.dx[q], Q.dy[q], Q.dz[q], Q.time[q],
+                                           CRT_MASK_SHADOW, 0.001f, Q.tmax[q], h, &stack[threadIdx.x], err, st);
+    done++;
+    if (occ) continue;
+    const uint32_t tg = Q.target[q];
+    const float cx = Q.cx[q], cy = Q.cy[q], cz = Q.cz[q];
+    if (tg & kFilmTarget) {  // the path ended at this vertex: its radiance already sits in the staging plane
+      const uint32_t f = tg & ~kFilmTarget;
+      staging[f] = staging[f] + cx;
+      staging[(size_t)staging_plane + f] = staging[(size_t)staging_plane + f] + cy;
+      staging[2 * (size_t)staging_plane + f] = staging[2 * (size_t)staging_plane + f] + cz;
+    } else {
+      N.lx[tg] = N.lx[tg] + cx; N.ly[tg] = N.ly[tg] + cy; N.lz[tg] = N.lz[tg] + cz;
+    }
+  }
+  if (err) atomicOr(&C->err, err);
+  if (STATS) {
+    auto wave_sum = [](uint32_t v) { for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64); return v; };
+    const bool lead = (threadIdx.x & 63) == 0;
+    for (int k = 0; k < 2; k++) {
+      const uint32_t a = wave_sum(st.queries[k]), b = wave_sum(st.nodes[k]), c = wave_sum(st.leaves[k]);
+      const uint32_t d = wave_sum(st.packets[k]), e = wave_sum(st.prims[k]);
+      if (lead) {
+        atomicAdd((unsigned long long *)&tstats->queries[k], (unsigned long long)a);
+        atomicAdd((unsigned long long *)&tstats->nodes[k], (unsigned long long)b);
+        atomicAdd((unsigned long long *)&tstats->leaves[k], (unsigned long long)c);
+        atomicAdd((unsigned long long *)&tstats->packets[k], (unsigned long long)d);
+        atomicAdd((unsigned long long *)&tstats->prims[k], (unsigned long long)e);
+      }
+    }
+    const uint32_t a = wave_sum(st.accepted), b = wave_sum(st.descents), c = wave_sum(done);
+    if (lead) {
+      atomicAdd((unsigned long long *)&tstats->accepted_hits, (unsigned long long)a);
+      atomicAdd((unsigned long long *)&tstats->instance_descents, (unsigned long long)b);
+      atomicAdd((unsigned long long *)&tstats->rays, (unsigned long long)c);
+    }
+  }
+}
+
+// Between bounces: the buffer just consumed becomes the next output; the shadow queue empties.
+__global__ void k_flip(Counters *C, int consumed) {
+  C->count[consumed] = 0;
+  C->n_shadow = 0;
+}
+
+// ---- resolve: sum += color, in sample order; weight_sum += wx*wy = 1 (tracer.rs:599-600) ----
+__global__ __launch_bounds__(kBlock) void k_resolve(const float *staging, uint32_t staging_plane, uint32_t n_pix,
+                                                    uint32_t n_samples, float *film /* 4 planes: r g b w */) {
+  for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < n_pix; p += gridDim.x * kBlock) {
+    float r = film[p], g = film[(size_t)n_pix + p], b = film[2 * (size_t)n_pix + p], w = film[3 * (size_t)n_pix + p];
+    for (uint32_t s = 0; s < n_samples; s++) {
+      const size_t f = (size_t)s * n_pix + p;
+      r = r + staging[f];
+      g = g + staging[(size_t)staging_plane + f];
+      b = b + staging[2 * (size_t)staging_plane + f];
+      w = w + 1.0f;
+    }
+    film[p] = r; film[(size_t)n_pix + p] = g; film[2 * (size_t)n_pix + p] = b; film[3 * (size_t)n_pix + p] = w;
+  }
+}
+
+// pixel = sum / weight_sum (tracer.rs:630-634); rgb interleaved per owned pixel.
+__global__ __launch_bounds__(kBlock) void k_film_out(const float *film, uint32_t n_pix, float *rgb) {
+  for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < n_pix; p += gridDim.x * kBlock) {
+    const float w = film[3 * (size_t)n_pix + p];
+    const float r = film[p], g = film[(size_t)n_pix + p], b = film[2 * (size_t)n_pix + p];
+    // weight_sum > 0 always holds for box/triangle (w = taken); the fallback arm divides by `taken` = w too.
+    rgb[3 * (size_t)p] = r / w; rgb[3 * (size_t)p + 1] = g / w; rgb[3 * (size_t)p + 2] = b / w;
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// Host side: Renderer (tracer.rs:137-148) over the kernels above
+// ---------------------------------------------------------------------------------------------
+struct Renderer {
+  std::shared_ptr<Scene> scene;
+  Params P{};
+  std::vector<uint32_t> pixels;  // owned pixels (linear buffer index), tile order
+  uint32_t cap_samples = 0;      // samples per batch the buffers are sized for
+  char *blob = nullptr;
+  size_t blob_bytes = 0;
+  PathSoA S[2]{};
+  HitSoA H{};
+  ShadowSoA Q{};
+  Counters *C = nullptr;
+  float *staging = nullptr;
+  float *film = nullptr;
+  CrtMaterial *d_materials = nullptr;
+  CrtLight *d_lights = nullptr;
+  uint32_t *d_pixels = nullptr;
+  int grid = 2048;
+  hipStream_t last_stream = nullptr;
+  bool profile = false;
+  struct Ev { hipEvent_t a, b; int cls; };
+  std::vector<Ev> events;
+  double prof_ms[4] = {0, 0, 0, 0};
+  uint64_t prof_launches[4] = {0, 0, 0, 0};
+
+  ~Renderer() {
+    drain_events();
+    if (blob) (void)hipFree(blob);
+    if (C) (void)hipFree(C);
+    if (film) (void)hipFree(film);
+    if (d_materials) (void)hipFree(d_materials);
+    if (d_lights) (void)hipFree(d_lights);
+    if (d_pixels) (void)hipFree(d_pixels);
+  }
+
+  void drain_events() {
+    for (Ev &e : events) {
+      float ms = 0.0f;
+      if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+        prof_ms[e.cls] += ms;
+        prof_launches[e.cls]++;
+      }
+      (void)hipEventDestroy(e.a);
+      (void)hipEventDestroy(e.b);
+    }
+    events.clear();
+  }
+
+  int ensure_buffers(uint32_t n_samples) {
+    if (n_samples <= cap_samples && blob) return CRT_OK;
+    if (blob) { (void)hipFree(blob); blob = nullptr; }
+    const size_t cap = (size_t)P.n_pix * n_samples;
+    if (cap == 0 || cap >= (size_t)0x7fffffff) return CRT_ERR_BAD_ARG;
+    const size_t plane = (cap * 4 + 255) & ~size_t(255);
+    const size_t n_planes = 2 * 21 + 5 + 12 + 3;
+    blob_bytes = plane * n_planes;
+    if (!CRT_HIP_OK(hipMalloc(&blob, blob_bytes))) return CRT_ERR_NO_DEVICE;
+    size_t k = 0;
+    auto next = [&]() { return blob + plane * (k++); };
+    for (int b = 0; b < 2; b++) {
+      PathSoA &s = S[b];
+      float **fl[] = {&s.ox, &s.oy, &s.oz, &s.dx, &s.dy, &s.dz, &s.time, &s.bx, &s.by, &s.bz, &s.lx, &s.ly, &s.lz,
+                      &s.px, &s.py, &s.pz, &s.ppdf};
+      for (float **f : fl) *f = reinterpret_cast<float *>(next());
+      uint32_t **ul[] = {&s.pattern, &s.pix, &s.meta, &s.aux};
+      for (uint32_t **u : ul) *u = reinterpret_cast<uint32_t *>(next());
+    }
+    H.t = (float *)next(); H.nx = (float *)next(); H.ny = (float *)next(); H.nz = (float *)next();
+    H.geom = (uint32_t *)next();
+    float **ql[] = {&Q.ox, &Q.oy, &Q.oz, &Q.dx, &Q.dy, &Q.dz, &Q.tmax, &Q.time, &Q.cx, &Q.cy, &Q.cz};
+    for (float **f : ql) *f = reinterpret_cast<float *>(next());
+    Q.target = (uint32_t *)next();
+    staging = (float *)next(); (void)next(); (void)next();  // three contiguous planes
+    staging_plane = (uint32_t)(plane / 4);
+    cap_samples = n_samples;
+    return CRT_OK;
+  }
+  uint32_t staging_plane = 0;
+
+  template <class F>
+  void timed(int cls, hipStream_t st, F &&launch) {
+    if (!profile) { launch(); return; }
+    Ev e; e.cls = cls;
+    (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b);
+    (void)hipEventRecord(e.a, st);
+    launch();
+    (void)hipEventRecord(e.b, st);
+    events.push_back(e);
+  }
+
+  int render(uint32_t sample_begin, uint32_t n_samples, hipStream_t st, CrtTravStats *d_tstats) {
+    if (n_samples == 0) return CRT_OK;
+    if (n_samples > 0xffffu) return CRT_ERR_BAD_ARG;
+    int rc = ensure_buffers(n_samples);
+    if (rc != CRT_OK) return rc;
+    last_stream = st;
+    Params p = P;
+    p.sample_begin = sample_begin;
+    timed(3, st, [&] { hipLaunchKernelGGL(k_generate, dim3(grid), dim3(kBlock), 0, st, p, S[0], C, sample_begin, n_samples); });
+    int cur = 0;
+    for (uint32_t it = 0; it <= P.max_depth; it++) {
+      if (d_tstats) timed(0, st, [&] { hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kBlock), 0, st, p, S[cur], H, C, cur, d_tstats); });
+      else timed(0, st, [&] { hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kBlock), 0, st, p, S[cur], H, C, cur, d_tstats); });
+      timed(1, st, [&] { hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, st, p, S[cur], S[1 - cur], H, Q, C, cur, staging, staging_plane); });
+      if (P.n_lights > 0 && P.strategy != CRT_STRATEGY_BSDF) {
+        if (d_tstats) timed(2, st, [&] { hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(kBlock), 0, st, p, S[1 - cur], Q, C, staging, staging_plane, d_tstats); });
+        else timed(2, st, [&] { hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(kBlock), 0, st, p, S[1 - cur], Q, C, staging, staging_plane, d_tstats); });
+      }
+      timed(3, st, [&] { hipLaunchKernelGGL(k_flip, dim3(1), dim3(1), 0, st, C, cur); });
+      cur = 1 - cur;
+    }
+    timed(3, st, [&] { hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(kBlock), 0, st, staging, staging_plane, P.n_pix, n_samples, film); });
+    return CRT_HIP_OK(hipGetLastError()) ? CRT_OK : CRT_ERR_NO_DEVICE;
+  }
+};
+
+}  // namespace crt
+
+struct CrtRenderer { crt::Renderer r; };
+
+using namespace crt;
+
+extern "C" {
+
+void crt_camera_new(CrtCamera *c, const float lookfrom[3], const float lookat[3], const float vup[3], float vfov_deg,
+                    float aspect, float aperture, float focus_dist) {  // camera.rs:27-63 (host-side setup)
+  if (!c) return;
+  auto sub = [](const float a[3], const float b[3], float o[3]) { for (int i = 0; i < 3; i++) o[i] = a[i] - b[i]; };
+  auto nrm = [](float a[3]) {
+    const float l = sqrtf((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]);
+    for (int i = 0; i < 3; i++) a[i] = a[i] / l;
+  };
+  auto crs = [](const float a[3], const float b[3], float o[3]) {
+    o[0] = a[1] * b[2] - b[1] * a[2]; o[1] = a[2] * b[0] - b[2] * a[0]; o[2] = a[0] * b[1] - b[0] * a[1];
+  };
+  const float theta = vfov_deg * 3.14159265358979323846f / 180.0f;
+  const float h = tanf(theta / 2.0f);
+  const float viewport_height = 2.0f * h;
+  const float viewport_width = aspect * viewport_height;
+  float w[3], u[3], v[3];
+  sub(lookfrom, lookat, w); nrm(w);
+  crs(vup, w, u); nrm(u);
+  crs(w, u, v);
+  for (int i = 0; i < 3; i++) {
+    c->origin[i] = lookfrom[i];
+    c->horizontal[i] = u[i] * (focus_dist * viewport_width);
+    c->vertical[i] = v[i] * (focus_dist * viewport_height);
+    c->lower_left[i] = ((lookfrom[i] - c->horizontal[i] / 2.0f) - c->vertical[i] / 2.0f) - w[i] * focus_dist;
+    c->u[i] = u[i];
+    c->v[i] = v[i];
+  }
+  c->lens_radius = aperture / 2.0f;
+}
+
+CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, size_t n_materials, const CrtLight *lights,
+                              size_t n_lights, const CrtCamera *camera, const CrtRenderSettings *settings,
+                              uint32_t tile_rank, uint32_t tile_world) {
+  if (!scene || !camera || !settings || (n_materials && !materials) || (n_lights && !lights)) return nullptr;
+  if (tile_world == 0 || tile_rank >= tile_world) return nullptr;
+  if (settings->variance_threshold != 0.0f) return nullptr;  // adaptive stopping is a per-pixel host loop: not here
+  if (n_materials < scene->p->n_geoms) return nullptr;        // one material per geom_id (rt_world.rs:111-122)
+  if (settings->max_depth > 0xffffu) return nullptr;
+  if (scene->p->ensure_device() != CRT_OK) return nullptr;
+  CrtRenderer *R = new (std::nothrow) CrtRenderer();
+  if (!R) return nullptr;
+  Renderer &r = R->r;
+  r.scene = scene->p;
+  Params &P = r.P;
+  P.scene = scene->p->dev->view;
+  P.n_lights = (uint32_t)n_lights;
+  P.camera = *camera;
+  P.width = settings->width; P.height = settings->height; P.max_depth = settings->max_depth;
+  P.frame = settings->frame; P.strategy = settings->strategy; P.filter_kind = settings->filter_kind;
+  P.filter_radius = settings->filter_radius;
+  P.has_motion = scene->p->has_motion ? 1u : 0u;
+  // Pixel-tile shard: 16x16 tiles (tracer.rs:424, :1671-1686) dealt round-robin over the ranks.
+  const uint32_t tx = (P.width + 15) / 16, ty = (P.height + 15) / 16;
+  for (uint32_t t = 0; t < tx * ty; t++) {
+    if (t % tile_world != tile_rank) continue;
+    const uint32_t x0 = (t % tx) * 16, y0 = (t / tx) * 16;
+    for (uint32_t y = y0; y < y0 + 16 && y < P.height; y++)
+      for (uint32_t x = x0; x < x0 + 16 && x < P.width; x++) r.pixels.push_back(y * P.width + x);
+  }
+  P.n_pix = (uint32_t)r.pixels.size();
+  bool ok = P.n_pix > 0;
+  ok = ok && CRT_HIP_OK(hipMalloc(&r.C, sizeof(Counters))) && CRT_HIP_OK(hipMemset(r.C, 0, sizeof(Counters)));
+  ok = ok && CRT_HIP_OK(hipMalloc(&r.film, (size_t)P.n_pix * 16)) && CRT_HIP_OK(hipMemset(r.film, 0, (size_t)P.n_pix * 16));
+  ok = ok && CRT_HIP_OK(hipMalloc(&r.d_pixels, (size_t)P.n_pix * 4)) &&
+       CRT_HIP_OK(hipMemcpy(r.d_pixels, r.pixels.data(), (size_t)P.n_pix * 4, hipMemcpyHostToDevice));
+  if (ok && n_materials) {
+    ok = CRT_HIP_OK(hipMalloc(&r.d_materials, n_materials * sizeof(CrtMaterial))) &&
+         CRT_HIP_OK(hipMemcpy(r.d_materials, materials, n_materials * sizeof(CrtMaterial), hipMemcpyHostToDevice));
+  }
+  if (ok && n_lights) {
+    ok = CRT_HIP_OK(hipMalloc(&r.d_lights, n_lights * sizeof(CrtLight))) &&
+         CRT_HIP_OK(hipMemcpy(r.d_lights, lights, n_lights * sizeof(CrtLight), hipMemcpyHostToDevice));
+  }
+  if (!ok) { delete R; return nullptr; }
+  P.materials = r.d_materials; P.lights = r.d_lights; P.pixel_index = r.d_pixels;
+  hipDeviceProp_t prop;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) r.grid = prop.multiProcessorCount * 8;
+  return R;
+}
+void crt_renderer_free(CrtRenderer *r) { delete r; }
+size_t crt_renderer_pixel_count(const CrtRenderer *r) { return r ? r->r.pixels.size() : 0; }
+int crt_renderer_pixel_indices(const CrtRenderer *r, uint32_t *out) {
+  if (!r || !out) return CRT_ERR_BAD_ARG;
+  std::memcpy(out, r->r.pixels.data(), r->r.pixels.size() * 4);
+  return CRT_OK;
+}
+int crt_render_samples(CrtRenderer *r, uint32_t sample_begin, uint32_t sample_count, void *stream) {
+  if (!r) return CRT_ERR_BAD_ARG;
+  return r->r.render(sample_begin, sample_count, (hipStream_t)stream, nullptr);
+}
+int crt_render_samples_stats(CrtRenderer *r, uint32_t sample_begin, uint32_t sample_count, void *stream,
+                             CrtTravStats *host_stats) {
+  if (!r || !host_stats) return CRT_ERR_BAD_ARG;
+  CrtTravStats *d = nullptr;
+  if (!CRT_HIP_OK(hipMalloc(&d, sizeof(CrtTravStats)))) return CRT_ERR_NO_DEVICE;
+  (void)hipMemsetAsync(d, 0, sizeof(CrtTravStats), (hipStream_t)stream);
+  int rc = r->r.render(sample_begin, sample_count, (hipStream_t)stream, d);
+  CrtTravStats h{};
+  if (rc == CRT_OK && !CRT_HIP_OK(hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream))) rc = CRT_ERR_NO_DEVICE;
+  if (!CRT_HIP_OK(hipStreamSynchronize((hipStream_t)stream))) rc = CRT_ERR_NO_DEVICE;
+  (void)hipFree(d);
+  if (rc == CRT_OK) {
+    for (int k = 0; k < 2; k++) {
+      host_stats->queries[k] += h.queries[k]; host_stats->nodes[k] += h.nodes[k]; host_stats->leaves[k] += h.leaves[k];
+      host_stats->packets[k] += h.packets[k]; host_stats->prims[k] += h.prims[k];
+    }
+    host_stats->accepted_hits += h.accepted_hits; host_stats->instance_descents += h.instance_descents;
+    host_stats->rays += h.rays;
+  }
+  return rc;
+}
+int crt_film_resolve(CrtRenderer *r, float *d_rgb, void *stream) {
+  if (!r || !d_rgb) return CRT_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_film_out, dim3(r->r.grid), dim3(kBlock), 0, (hipStream_t)stream, r->r.film, r->r.P.n_pix, d_rgb);
+  return CRT_HIP_OK(hipGetLastError()) ? CRT_OK : CRT_ERR_NO_DEVICE;
+}
+int crt_film_read(CrtRenderer *r, float *host_rgb) {
+  if (!r || !host_rgb) return CRT_ERR_BAD_ARG;
+  float *d = nullptr;
+  const size_t bytes = (size_t)r->r.P.n_pix * 12;
+  if (!CRT_HIP_OK(hipMalloc(&d, bytes))) return CRT_ERR_NO_DEVICE;
+  int rc = crt_film_resolve(r, d, r->r.last_stream);
+  if (rc == CRT_OK && !CRT_HIP_OK(hipStreamSynchronize(r->r.last_stream))) rc = CRT_ERR_NO_DEVICE;
+  if (rc == CRT_OK && !CRT_HIP_OK(hipMemcpy(host_rgb, d, bytes, hipMemcpyDeviceToHost))) rc = CRT_ERR_NO_DEVICE;
+  (void)hipFree(d);
+  return rc;
+}
+int crt_film_clear(CrtRenderer *r, void *stream) {
+  if (!r) return CRT_ERR_BAD_ARG;
+  bool ok = CRT_HIP_OK(hipMemsetAsync(r->r.film, 0, (size_t)r->r.P.n_pix * 16, (hipStream_t)stream));
+  ok = ok && CRT_HIP_OK(hipMemsetAsync(r->r.C, 0, sizeof(Counters), (hipStream_t)stream));
+  return ok ? CRT_OK : CRT_ERR_NO_DEVICE;
+}
+int crt_render_stats(CrtRenderer *r, CrtRayStats *out) {
+  if (!r || !out) return CRT_ERR_BAD_ARG;
+  Counters h;
+  if (!CRT_HIP_OK(hipStreamSynchronize(r->r.last_stream))) return CRT_ERR_NO_DEVICE;
+  if (!CRT_HIP_OK(hipMemcpy(&h, r->r.C, sizeof h, hipMemcpyDeviceToHost))) return CRT_ERR_NO_DEVICE;
+  out->camera_rays = h.stats[0]; out->closest_hit = h.stats[1]; out->shadow_rays = h.stats[2];
+  out->vertices = h.stats[3]; out->rr_tested = h.stats[4]; out->rr_killed = h.stats[5];
+  out->ended_escaped = h.stats[6]; out->ended_depth = h.stats[7];
+  return h.err ? CRT_ERR_STACK : CRT_OK;
+}
+int crt_renderer_profile(CrtRenderer *r, int enable) {
+  if (!r) return CRT_ERR_BAD_ARG;
+  r->r.drain_events();
+  r->r.profile = enable != 0;
+  for (int k = 0; k < 4; k++) { r->r.prof_ms[k] = 0; r->r.prof_launches[k] = 0; }
+  return CRT_OK;
+}
+int crt_renderer_profile_read(CrtRenderer *r, double out_ms[4], uint64_t out_launches[4]) {
+  if (!r || !out_ms || !out_launches) return CRT_ERR_BAD_ARG;
+  r->r.drain_events();
+  for (int k = 0; k < 4; k++) { out_ms[k] = r->r.prof_ms[k]; out_launches[k] = r->r.prof_launches[k]; }
+  return CRT_OK;
+}
+
+}  // extern "C"

@@ -170,7 +170,10 @@ static v3 trace_path(const OraRenderJob *job, const OraRay *r, OraSampler sample
     VertexRec vrec;
     vrec.atten = atten; vrec.segment_emit = v3_splat(0.0f); vrec.emit_here = emit_here; vrec.nee = nee;
     vrec.factor = v3_splat(0.0f); vrec.next_emit = v3_splat(0.0f); vrec.next_emit_weight = 1.0f;
-    if (forward) L = v3_add(L, v3_mul(beta, v3_add(emit_here, nee)));
+    if (forward) { /* two separate adds: the second is what a deferred shadow test contributes */
+      L = v3_add(L, v3_mul(beta, emit_here));
+      L = v3_add(L, v3_mul(beta, nee));
+    }
 
     /* === 2. bounce (tracer.rs:1459-1523) === */
     OraScatter sample;
