@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py — Mray/s of the wavefront path tracer on BASELINE.json's configs[1].
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Workload (config.workload): samples/cornellbox.usda at 1920x1080, scene-default depth 32, triangle filter r=1,
+adaptive stopping off (variance 0), frame 0. A "step" is ONE wavefront batch: `--spp-per-step` samples (default
+8) of every pixel a rank owns — generate, then up to depth+1 rounds of extend / shade / shadow, then the film
+fold — with the scene, the path-state planes and the film resident in HBM before the timed region starts.
+1024 spp is 128 such steps; the default K is smaller so the run finishes in about a minute.
+
+Metric (stats.rs:150-152): Mray/s = (closest_hit + shadow_rays) / render seconds / 1e6, summed
+over all ranks; the timed region is K steps bracketed by barrier + synchronize, MAX over ranks.
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL). The frame's 16x16 tiles are dealt round-robin
+to the ranks; each rank traces `--spp-per-step * N` samples of its own tiles per step, so per-GPU work per step is
+fixed as N grows ("weak": N GPUs advance the frame N times as many spp per step). Tile ownership is disjoint, so
+the only collective is ONE RCCL all_gather of the per-rank tile buffers after the last step (inside the timed
+region), plus the 64-bit ray counters.
+
+roofline: for the dominant kernel (k_extend, the BVH4 closest-hit traversal): algorithmic bytes (SURVEY §8d
+formula, from the stats build of the same kernels on the same batch) over the HIP-event duration of its launches
+in the timed region, against the 8 TB/s HBM peak. cpu_baseline: the oracle (CPU restatement, "port") rendering a
+bounded sample of the same workload on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--spp-per-step", type=int, default=8)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--scene", default="cornellbox")
+    ap.add_argument("--depth", type=int, default=None, help="override max depth (default: the scene's, 32)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-spp", type=int, default=2, help="spp of the bounded CPU-baseline sample")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from __graft_entry__ import load_package
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 through torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+
+    crt = load_package()
+    crt.lib()
+    path = os.path.join(ROOT, "scenes", args.scene + ".usda")
+    r, desc = crt.load_usda(path, args.width, args.height, args.depth, rank=rank, world=world)
+    spp_step = args.spp_per_step * world
+    stream = torch.cuda.current_stream()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sample = 0
+    for _ in range(args.warmup):
+        r.render_samples(sample, spp_step, stream)
+        sample += spp_step
+    barrier()
+    r.clear(stream)  # film sums and ray counters restart; buffers stay resident
+    r.profile(True)
+    n_pix_total = args.width * args.height
+    d_rgb = torch.empty(r.n_pix * 3, dtype=torch.float32, device="cuda")
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        r.render_samples(k * spp_step, spp_step, stream)
+    r.film_to(d_rgb, stream)
+    if dist is not None:  # the one data-path collective: gather the tile buffers (padded to the largest shard)
+        n_max = (n_pix_total // 256 // world + 1) * 256
+        send = torch.zeros(n_max * 3, dtype=torch.float32, device="cuda")
+        send[: r.n_pix * 3] = d_rgb
+        recv = torch.empty(world * n_max * 3, dtype=torch.float32, device="cuda")
+        dist.all_gather_into_tensor(recv, send)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    st = r.stats()
+    prof = r.profile_read()
+    r.profile(False)
+
+    rays = torch.tensor([st.closest_hit, st.shadow_rays, st.camera_rays, st.vertices], dtype=torch.int64, device="cuda")
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    rays = rays.cpu().tolist()
+    elapsed = float(tmax.item())
+    total_rays = rays[0] + rays[1]
+    value = total_rays / elapsed / 1e6
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (k_extend), N=1 figures of rank 0 ----
+    ext, sh = r.render_samples_stats(0, spp_step, stream)  # stats build, same batch shape; not timed
+    steps_bytes = ext.algorithmic_bytes() * args.steps    # every timed step runs the same batch shape
+    # (per-step counts differ only through the sample index; one batch is representative to < 1 %)
+    ext_ms, ext_n = prof["extend"]["ms"], prof["extend"]["launches"]
+    achieved = steps_bytes / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
+    roofline = {
+        "kernel": "k_extend (BVH4 closest-hit traversal)",
+        "bound": "hbm",
+        "achieved": round(achieved, 2),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 5),
+        "traffic": _traffic_from_profile(),
+        "launches": ext_n,
+        "avg_launch_ms": round(ext_ms / max(ext_n, 1), 5),
+        "bytes_per_launch": int(steps_bytes / max(ext_n, 1)),
+        "bytes_per_ray": round(ext.algorithmic_bytes() / max(int(ext.rays), 1), 1),
+        "kernel_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
+    }
+
+    cpu = None
+    if not args.no_cpu_baseline:
+        cpu = _cpu_baseline(crt, desc, args)
+
+    out = {
+        "metric": "Mray/s (closest-hit + shadow queries) of the path-tracing integrator",
+        "value": round(value, 2),
+        "unit": "Mray/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic-free: the reference's own sample scene file (scenes/%s.usda), seeded sampler, frame 0" % args.scene,
+        "config": {
+            "workload": "samples/%s.usda %dx%d, %d spp per step per GPU-share (x%d GPUs), depth %d, triangle r=1, "
+                        "variance 0; %d steps = %d spp" % (args.scene, args.width, args.height, args.spp_per_step, world,
+                                                           r.settings.max_depth, args.steps, args.steps * spp_step),
+            "spp_per_step": spp_step,
+            "paths_per_step_per_gpu": r.n_pix * spp_step,
+            "rays_total": total_rays,
+            "closest_hit": rays[0],
+            "shadow_rays": rays[1],
+            "camera_rays": rays[2],
+            "mean_path_length": round(rays[3] / max(rays[2], 1), 3),
+            "seconds": round(elapsed, 4),
+            "spp_per_second": round(args.steps * spp_step / elapsed, 2),
+            "sharding": "16x16 pixel tiles round-robin over ranks; one RCCL all_gather of tile buffers" if world > 1 else "none",
+        },
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def _traffic_from_profile():
+    """HBM bytes per k_extend launch from the committed rocprofv3 --pmc passes (profiles/*_pmc.json), or null."""
+    p = os.path.join(ROOT, "profiles", "r01_pmc_extend.json")
+    if os.path.exists(p):
+        try:
+            with open(p) as f:
+                return json.load(f).get("hbm_bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
+def _cpu_baseline(crt, desc, args):
+    """The oracle (kind 'port': CPU restatement of the reference's algorithm, all host cores, 16x16 tiles as
+    tracer.rs:424-459) on a bounded sample of the same workload: the full frame at --cpu-spp samples."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ora_world
+    cores = os.cpu_count() or 1
+    o = ora_world.OracleRenderer(desc, crt.usda, max_depth=args.depth, forward=0)
+    t0 = time.perf_counter()
+    _, st = o.render(args.cpu_spp, threads=cores)
+    dt = time.perf_counter() - t0
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except Exception:
+        pass
+    return {
+        "value": round(st.total_rays() / dt / 1e6, 3),
+        "unit": "Mray/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%dx%d full frame at %d spp (%d rays, %.1f s), reference-order estimator, host: %s" % (
+            args.width, args.height, args.cpu_spp, st.total_rays(), dt, model),
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -75,11 +75,11 @@ class CrtTravStats(C.Structure):
         return d
 
     def algorithmic_bytes(self):
-        """48 (ray in) + 32 (hit out) per ray + 128/node + 16/leaf + 192/packet + 64/scalar
-        prim test + 128/accepted hit + 112/instance descent."""
+        """SURVEY §8(d), verbatim: bytes(ray) = 48 (ray in) + 32 (hit out) + 128*nodes + 16*leaves + 192*packets
+        + 128*accepted_hits + 112*instance_descents, summed over the rays of the launches counted."""
         n = sum
         return (80 * int(self.rays) + 128 * n(self.nodes) + 16 * n(self.leaves) + 192 * n(self.packets) +
-                64 * n(self.prims) + 128 * int(self.accepted_hits) + 112 * int(self.instance_descents))
+                128 * int(self.accepted_hits) + 112 * int(self.instance_descents))
 
 
 _MAT_FIELDS = [
@@ -569,10 +569,10 @@ class Renderer:
         _check(lib().crt_render_samples(self.h, sample_begin, sample_count, _stream_ptr(stream)), "crt_render_samples")
 
     def render_samples_stats(self, sample_begin, sample_count, stream=None):
-        st = CrtTravStats()
-        _check(lib().crt_render_samples_stats(self.h, sample_begin, sample_count, _stream_ptr(stream), C.byref(st)),
+        st = (CrtTravStats * 2)()
+        _check(lib().crt_render_samples_stats(self.h, sample_begin, sample_count, _stream_ptr(stream), st),
                "crt_render_samples_stats")
-        return st
+        return st[0], st[1]  # extend (closest-hit) launches, shadow (any-hit) launches
 
     def film_to(self, d_rgb, stream=None):
         _check(lib().crt_film_resolve(self.h, d_rgb.data_ptr(), _stream_ptr(stream)), "crt_film_resolve")

@@ -566,7 +566,7 @@ struct Renderer {
       else timed(0, st, [&] { hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kBlock), 0, st, p, S[cur], H, C, cur, d_tstats); });
       timed(1, st, [&] { hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, st, p, S[cur], S[1 - cur], H, Q, C, cur, staging, staging_plane); });
       if (P.n_lights > 0 && P.strategy != CRT_STRATEGY_BSDF) {
-        if (d_tstats) timed(2, st, [&] { hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(kBlock), 0, st, p, S[1 - cur], Q, C, staging, staging_plane, d_tstats); });
+        if (d_tstats) timed(2, st, [&] { hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(kBlock), 0, st, p, S[1 - cur], Q, C, staging, staging_plane, d_tstats + 1); });
         else timed(2, st, [&] { hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(kBlock), 0, st, p, S[1 - cur], Q, C, staging, staging_plane, d_tstats); });
       }
       timed(3, st, [&] { hipLaunchKernelGGL(k_flip, dim3(1), dim3(1), 0, st, C, cur); });
@@ -678,23 +678,26 @@ int crt_render_samples(CrtRenderer *r, uint32_t sample_begin, uint32_t sample_co
   return r->r.render(sample_begin, sample_count, (hipStream_t)stream, nullptr);
 }
 int crt_render_samples_stats(CrtRenderer *r, uint32_t sample_begin, uint32_t sample_count, void *stream,
-                             CrtTravStats *host_stats) {
+                             CrtTravStats host_stats[2]) {
   if (!r || !host_stats) return CRT_ERR_BAD_ARG;
   CrtTravStats *d = nullptr;
-  if (!CRT_HIP_OK(hipMalloc(&d, sizeof(CrtTravStats)))) return CRT_ERR_NO_DEVICE;
-  (void)hipMemsetAsync(d, 0, sizeof(CrtTravStats), (hipStream_t)stream);
+  if (!CRT_HIP_OK(hipMalloc(&d, 2 * sizeof(CrtTravStats)))) return CRT_ERR_NO_DEVICE;
+  (void)hipMemsetAsync(d, 0, 2 * sizeof(CrtTravStats), (hipStream_t)stream);
   int rc = r->r.render(sample_begin, sample_count, (hipStream_t)stream, d);
-  CrtTravStats h{};
-  if (rc == CRT_OK && !CRT_HIP_OK(hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream))) rc = CRT_ERR_NO_DEVICE;
+  CrtTravStats h[2] = {};
+  if (rc == CRT_OK && !CRT_HIP_OK(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream))) rc = CRT_ERR_NO_DEVICE;
   if (!CRT_HIP_OK(hipStreamSynchronize((hipStream_t)stream))) rc = CRT_ERR_NO_DEVICE;
   (void)hipFree(d);
   if (rc == CRT_OK) {
-    for (int k = 0; k < 2; k++) {
-      host_stats->queries[k] += h.queries[k]; host_stats->nodes[k] += h.nodes[k]; host_stats->leaves[k] += h.leaves[k];
-      host_stats->packets[k] += h.packets[k]; host_stats->prims[k] += h.prims[k];
+    for (int w = 0; w < 2; w++) {
+      for (int k = 0; k < 2; k++) {
+        host_stats[w].queries[k] += h[w].queries[k]; host_stats[w].nodes[k] += h[w].nodes[k];
+        host_stats[w].leaves[k] += h[w].leaves[k]; host_stats[w].packets[k] += h[w].packets[k];
+        host_stats[w].prims[k] += h[w].prims[k];
+      }
+      host_stats[w].accepted_hits += h[w].accepted_hits; host_stats[w].instance_descents += h[w].instance_descents;
+      host_stats[w].rays += h[w].rays;
     }
-    host_stats->accepted_hits += h.accepted_hits; host_stats->instance_descents += h.instance_descents;
-    host_stats->rays += h.rays;
   }
   return rc;
 }

@@ -222,9 +222,10 @@ int crt_render_stats(CrtRenderer *r, CrtRayStats *out);
  * out_ms[k] = summed duration, out_launches[k] = launches. Enabled by crt_renderer_profile(r, 1). */
 int crt_renderer_profile(CrtRenderer *r, int enable);
 int crt_renderer_profile_read(CrtRenderer *r, double out_ms[4], uint64_t out_launches[4]);
-/* Traversal counters of the extend+shadow kernels for one batch (separate stats build of the kernels). */
+/* Traversal counters for one batch, from the stats build of the kernels: host_stats[0] += the extend
+ * (closest-hit) launches, host_stats[1] += the shadow (any-hit) launches. Synchronises the stream. */
 int crt_render_samples_stats(CrtRenderer *r, uint32_t sample_begin, uint32_t sample_count, void *stream,
-                             CrtTravStats *host_stats);
+                             CrtTravStats host_stats[2]);
 
 /* Library / device info. crt_last_error: text of the last failing HIP call on this thread ("" if none). */
 const char *crt_version(void);
