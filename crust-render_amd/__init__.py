@@ -20,7 +20,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcrt_amd.so")
+LIB_PATH = os.environ.get("CRT_AMD_LIB") or os.path.join(_HERE, "libcrt_amd.so")  # env: A/B builds only
 CSRC = os.path.join(_HERE, "csrc")
 
 MASK_CAMERA, MASK_SHADOW, MASK_INDIRECT, MASK_ALL = 1, 2, 4, 0xFFFFFFFF

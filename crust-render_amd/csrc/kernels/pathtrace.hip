@@ -20,6 +20,7 @@
 //   shadow   : any-hit traversal of the shadow queue; unoccluded requests add their contribution
 //   resolve  : staging planes are folded into the film in sample order (sum += color, tracer.rs:599)
 // Path state is struct-of-arrays so every stage's loads and stores are unit-stride across a wave.
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -33,6 +34,17 @@ using namespace dev;
 
 namespace {
 
+// Occupancy targets (second __launch_bounds__ argument = waves per SIMD; caps the VGPR allocation).
+#ifndef CRT_EXTEND_WAVES
+#define CRT_EXTEND_WAVES 3
+#endif
+#ifndef CRT_SHADE_WAVES
+#define CRT_SHADE_WAVES 2
+#endif
+#ifndef CRT_SHADOW_WAVES
+#define CRT_SHADOW_WAVES 4
+#endif
+
 enum { K_CAMERA = 0, K_PATH = 1, K_TIME = 2 };                 // tracer.rs:20-22 (off root)
 enum { K_NEE = 0, K_BSDF = 2, K_RR = 5 };                      // tracer.rs:23-28 (off vertex)
 constexpr int kRrStartBounce = 3;                              // tracer.rs:46
@@ -40,26 +52,31 @@ constexpr float kRrMinProb = 0.05f;                            // tracer.rs:47
 constexpr uint32_t kFilmTarget = 0x80000000u;
 constexpr uint32_t kPrevValid = 1u << 16, kPrevDelta = 1u << 17;
 
-// One set of path-state planes (struct of arrays, capacity `cap` each).
+// Path state: struct-of-arrays of 16-byte records, so each plane is read and written with one
+// 16-byte-per-lane (1 KiB per wave) instruction — the widest, most efficient global access on CDNA4.
 struct PathSoA {
-  float *ox, *oy, *oz, *dx, *dy, *dz, *time;
-  float *bx, *by, *bz;      // beta: the running throughput (tracer.rs:1114)
-  float *lx, *ly, *lz;      // L: radiance gathered so far
-  float *px, *py, *pz;      // previous vertex position (PrevBounce::rec.p, tracer.rs:899-906)
-  float *ppdf;              // previous bounce pdf
-  uint32_t *pattern;        // sampler state of the path's K_PATH domain
-  uint32_t *pix;            // index into the owned-pixel list
-  uint32_t *meta;           // n_rec (low 16) | remaining depth (high 16)
-  uint32_t *aux;            // sample-in-batch (low 16) | kPrevValid | kPrevDelta
+  float4 *a;    // origin.xyz, dir.x
+  float4 *b;    // dir.yz, beta.xy          beta: the running throughput (tracer.rs:1114)
+  float4 *c;    // beta.z, L.xyz            L: radiance gathered so far
+  uint4 *d;     // sampler pattern of the K_PATH domain | owned-pixel index |
+                // n_rec (low 16) + remaining depth (high 16) | sample-in-batch (low 16) + kPrevValid + kPrevDelta
+  float4 *e;    // previous vertex position + previous bounce pdf (PrevBounce, tracer.rs:899-906); lit scenes only
+  float *time;  // shutter time; scenes with motion only
 };
-struct HitSoA { float *t, *nx, *ny, *nz; uint32_t *geom; };  // geom: id | front_face << 31; ~0 = miss
-struct ShadowSoA { float *ox, *oy, *oz, *dx, *dy, *dz, *tmax, *time, *cx, *cy, *cz; uint32_t *target; };
+struct HitSoA { float4 *h; uint32_t *geom; };  // t, ray-facing normal; geom id | front_face << 31, ~0 = miss
+struct ShadowSoA { float4 *a, *b, *c; };       // origin + tmax; dir + time; contribution + target (bits)
 
+// Queues are segmented per workgroup: workgroup b owns slots [b * seg_cap, (b + 1) * seg_cap) of every
+// state buffer and of the shadow queue, and keeps the number of live entries of its segment in seg[]. A
+// workgroup compacts its own survivors with a wave ballot + popcount prefix and an LDS counter, so the
+// wavefront has NO global atomics on its data path (a single returning atomic per wave on one queue head
+// saturates near 88 M/s on this chip — more than the whole shade stage costs).
+constexpr int kMaxGrid = 16384;
 struct Counters {
-  uint32_t count[2];  // live paths in state buffer 0 / 1
-  uint32_t n_shadow;
   uint32_t err;
+  uint32_t pad;
   unsigned long long stats[8];  // RayStats (stats.rs:128-147) in declaration order
+  uint32_t seg[3][kMaxGrid];    // [0], [1]: live paths of state buffer 0 / 1; [2]: shadow requests
 };
 
 struct Params {
@@ -75,6 +92,7 @@ struct Params {
   uint32_t has_motion;
   const uint32_t *pixel_index;  // owned pixels: j * width + i
   uint32_t n_pix;
+  uint32_t seg_cap;             // slots per workgroup segment
 };
 
 __device__ __forceinline__ float light_weight(int s, float light_pdf, float bounce_pdf) {  // tracer.rs:85-92
@@ -94,35 +112,50 @@ __device__ __forceinline__ float bounce_weight(int s, float bounce_pdf, float li
   }
 }
 
-// Wave-aggregated append: every lane with `want` gets a unique slot; one atomic per wave.
-__device__ __forceinline__ uint32_t wave_append(bool want, uint32_t *counter) {
+// Segment-local append: every lane with `want` gets a unique slot of its workgroup's segment. The wave's
+// lanes are ranked with a ballot + popcount prefix; one LDS atomic per wave reserves the run.
+__device__ __forceinline__ uint32_t seg_append(bool want, uint32_t *lds_counter) {
   const unsigned long long mask = __ballot(want);
   if (mask == 0) return 0;
   const int lane = threadIdx.x & 63;
   const int leader = __ffsll((long long)mask) - 1;
   uint32_t base = 0;
-  if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+  if (lane == leader) base = atomicAdd(lds_counter, (uint32_t)__popcll(mask));
   base = __shfl(base, leader, 64);
   return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
-__device__ __forceinline__ void add_stat(unsigned long long *slot, uint32_t v) {
+// Per-workgroup reduction of a statistics counter: LDS first, then one global atomic per workgroup.
+__device__ __forceinline__ void add_stat(uint32_t *lds_slot, uint32_t v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  if ((threadIdx.x & 63) == 0 && v) atomicAdd(slot, (unsigned long long)v);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(lds_slot, v);
 }
 
 // ---- generate: PathSampler::new(...).new_domain(tile), camera sample, camera ray (tracer.rs:559-585) ----
 __global__ __launch_bounds__(kBlock) void k_generate(Params P, PathSoA S, Counters *C, uint32_t sample_begin,
                                                      uint32_t n_samples) {
+  __shared__ uint32_t sobol_tab[kSobolLdsWords];
+  sobol_tables_init(sobol_tab);
+  // Camera samples are dealt to the workgroup segments in round-robin chunks of one workgroup's width: slot k of
+  // segment b holds global sample g = ((k / 256) * G + b) * 256 + k % 256. Every segment is then a uniform
+  // sample of the frame (sky and geometry alike), so the per-segment work stays balanced at every bounce, while
+  // a wave still holds 64 consecutive pixels of one 16x16 tile (coherent primary rays).
   const size_t total = (size_t)P.n_pix * n_samples;
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
-    const uint32_t pix = (uint32_t)(i % P.n_pix), sl = (uint32_t)(i / P.n_pix);
+  const size_t seg0 = (size_t)blockIdx.x * P.seg_cap;
+  const size_t G = gridDim.x;
+  uint32_t seg_n = 0;
+  for (size_t k = threadIdx.x; k < P.seg_cap; k += kBlock) {
+    const size_t g = ((k / kBlock) * G + blockIdx.x) * kBlock + (k % kBlock);
+    if (g >= total) break;
+    seg_n = (uint32_t)k + 1;
+    const size_t i = seg0 + k;
+    const uint32_t pix = (uint32_t)(g % P.n_pix), sl = (uint32_t)(g / P.n_pix);
     const uint32_t lin = P.pixel_index[pix];
     const uint32_t px = lin % P.width, py = lin / P.width;
     const int tile = (int)(px >> 8) + (int)(py >> 8) * 4096;  // tracer.rs:543
     const Sampler root = new_domain(sampler_new((int)px, (int)py, P.frame, (int)(sample_begin + sl)), tile);
     float cam[4];
-    draw_sample4(new_domain(root, K_CAMERA), cam);
+    draw_sample4(new_domain(root, K_CAMERA), cam, sobol_tab);
     const float fx = filter_offset(P.filter_kind, P.filter_radius, cam[0]);
     const float fy = filter_offset(P.filter_kind, P.filter_radius, cam[1]);
     const float u = ((float)px + fx) / (float)P.width;
@@ -130,49 +163,52 @@ __global__ __launch_bounds__(kBlock) void k_generate(Params P, PathSoA S, Counte
     float time = 0.0f;
     if (P.has_motion) {  // tracer.rs:579-583
       float t4[4];
-      draw_sample4(new_domain(root, K_TIME), t4);
+      draw_sample4(new_domain(root, K_TIME), t4, sobol_tab);
       time = t4[0];
     }
     V3 o, d;
     camera_get_ray(P.camera, u, v, cam[2], cam[3], o, d);
-    S.ox[i] = o.x; S.oy[i] = o.y; S.oz[i] = o.z; S.dx[i] = d.x; S.dy[i] = d.y; S.dz[i] = d.z; S.time[i] = time;
-    S.bx[i] = 1.0f; S.by[i] = 1.0f; S.bz[i] = 1.0f;
-    S.lx[i] = 0.0f; S.ly[i] = 0.0f; S.lz[i] = 0.0f;
-    S.px[i] = 0.0f; S.py[i] = 0.0f; S.pz[i] = 0.0f; S.ppdf[i] = 0.0f;
-    S.pattern[i] = new_domain(root, K_PATH).pattern;  // tracer.rs:1101
-    S.pix[i] = pix;
-    S.meta[i] = (P.max_depth & 0xffffu) << 16;
-    S.aux[i] = sl;
+    S.a[i] = make_float4(o.x, o.y, o.z, d.x);
+    S.b[i] = make_float4(d.y, d.z, 1.0f, 1.0f);
+    S.c[i] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+    S.d[i] = make_uint4(new_domain(root, K_PATH).pattern /* tracer.rs:1101 */, pix, (P.max_depth & 0xffffu) << 16, sl);
+    if (P.has_motion) S.time[i] = time;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    C->count[0] = (uint32_t)total;
-    C->count[1] = 0;
-    C->n_shadow = 0;
-    atomicAdd(&C->stats[0], (unsigned long long)total);  // camera_rays (tracer.rs:585)
+  // live slots of this segment = 1 + the largest valid k over the workgroup (valid k form a prefix)
+  __shared__ uint32_t seg_max;
+  if (threadIdx.x == 0) seg_max = 0;
+  __syncthreads();
+  if (seg_n) atomicMax(&seg_max, seg_n);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    C->seg[0][blockIdx.x] = seg_max;
+    C->seg[1][blockIdx.x] = 0;
+    C->seg[2][blockIdx.x] = 0;
+    if (blockIdx.x == 0) atomicAdd(&C->stats[0], (unsigned long long)total);  // camera_rays (tracer.rs:585)
   }
 }
 
 // ---- extend: World::intersect (rt_world.rs:207-232) for every live path ----
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_extend(Params P, PathSoA S, HitSoA H, Counters *C, int cur,
+__global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_extend(Params P, PathSoA S, HitSoA H, Counters *C, int cur, int first,
                                                    CrtTravStats *tstats) {
   __shared__ uint32_t stack[kStackLds * kBlock];
-  const uint32_t n = C->count[cur];
+  const uint32_t n = C->seg[cur][blockIdx.x];
+  const uint32_t seg0 = blockIdx.x * P.seg_cap;
   LaneStats st = {};
   uint32_t err = 0, done = 0;
-  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    const float ox = S.ox[i], oy = S.oy[i], oz = S.oz[i], dx = S.dx[i], dy = S.dy[i], dz = S.dz[i];
-    const uint32_t n_rec = S.meta[i] & 0xffffu;
-    const uint32_t mask = n_rec == 0 ? CRT_MASK_CAMERA : CRT_MASK_INDIRECT;  // camera.rs:83, tracer.rs:1516-1519
+  for (uint32_t i = seg0 + threadIdx.x; i < seg0 + n; i += kBlock) {
+    const float4 A = S.a[i], B = S.b[i];
+    const float ox = A.x, oy = A.y, oz = A.z, dx = A.w, dy = B.x, dz = B.y;
+    const float time = P.has_motion ? S.time[i] : 0.0f;
+    // every path of the first round is a camera ray, every later one an indirect ray (camera.rs:83, tracer.rs:1516-1519)
+    const uint32_t mask = first ? CRT_MASK_CAMERA : CRT_MASK_INDIRECT;
     Hit h;
-    const bool hit = traverse<false, STATS>(P.scene, ox, oy, oz, dx, dy, dz, S.time[i], mask, 0.001f, CRT_INF, h,
+    const bool hit = traverse<false, STATS>(P.scene, ox, oy, oz, dx, dy, dz, time, mask, 0.001f, CRT_INF, h,
                                             &stack[threadIdx.x], err, st);
     if (hit) {
       const bool front = dot3(dx, dy, dz, h.nx, h.ny, h.nz) < 0.0f;  // scene.rs:356-359
-      H.t[i] = h.t;
-      H.nx[i] = front ? h.nx : -h.nx;
-      H.ny[i] = front ? h.ny : -h.ny;
-      H.nz[i] = front ? h.nz : -h.nz;
+      H.h[i] = make_float4(h.t, front ? h.nx : -h.nx, front ? h.ny : -h.ny, front ? h.nz : -h.nz);
       H.geom[i] = h.geom | (front ? 0x80000000u : 0u);
     } else {
       H.geom[i] = kInvalid;
@@ -204,15 +240,24 @@ __global__ __launch_bounds__(kBlock) void k_extend(Params P, PathSoA S, HitSoA H
 }
 
 // ---- shade: one iteration of trace_path's loop body for every live path (tracer.rs:1118-1530) ----
-__global__ __launch_bounds__(kBlock) void k_shade(Params P, PathSoA S, PathSoA N, HitSoA H, ShadowSoA Q, Counters *C,
-                                                  int cur, float *staging, uint32_t staging_plane) {
-  const uint32_t n = C->count[cur];
+__global__ __launch_bounds__(kBlock, CRT_SHADE_WAVES) void k_shade(Params P, PathSoA S, PathSoA N, HitSoA H, ShadowSoA Q, Counters *C,
+                                                  int cur, float4 *staging) {
+  __shared__ uint32_t sobol_tab[kSobolLdsWords];
+  __shared__ uint32_t lds_ctr[10];  // [0] survivors, [1] shadow requests, [2..8] statistics
+  const uint32_t n = C->seg[cur][blockIdx.x];
+  if (n == 0) {  // nothing lives in this segment (uniform per workgroup): publish empty outputs and leave
+    if (threadIdx.x == 0) { C->seg[1 - cur][blockIdx.x] = 0; C->seg[2][blockIdx.x] = 0; }
+    return;
+  }
+  if (threadIdx.x < 10) lds_ctr[threadIdx.x] = 0;
+  sobol_tables_init(sobol_tab);  // ends with a workgroup barrier
+  const uint32_t seg0 = blockIdx.x * P.seg_cap;
   uint32_t s_closest = 0, s_shadow = 0, s_vertices = 0, s_rr_t = 0, s_rr_k = 0, s_esc = 0, s_depth = 0;
-  const uint32_t stride = gridDim.x * kBlock;
-  const uint32_t rounds = (n + stride - 1) / stride;
+  const uint32_t rounds = (n + kBlock - 1) / kBlock;
   for (uint32_t round = 0; round < rounds; round++) {
-    const uint32_t i = round * stride + blockIdx.x * kBlock + threadIdx.x;
-    const bool active = i < n;
+    const uint32_t k_in = round * kBlock + threadIdx.x;
+    const uint32_t i = seg0 + k_in;
+    const bool active = k_in < n;
     bool alive = false, want_shadow = false;
     V3 L = splat(0.0f), beta = splat(1.0f);
     V3 n_o = splat(0.0f), n_d = splat(0.0f), sh_d = splat(0.0f), sh_c = splat(0.0f), hit_p = splat(0.0f);
@@ -220,11 +265,13 @@ __global__ __launch_bounds__(kBlock) void k_shade(Params P, PathSoA S, PathSoA N
     uint32_t meta = 0, aux = 0, pix = 0, pattern = 0;
     bool n_delta = false;
     if (active) {
-      const V3 ro = v3(S.ox[i], S.oy[i], S.oz[i]), rd = v3(S.dx[i], S.dy[i], S.dz[i]);
-      time = S.time[i];
-      beta = v3(S.bx[i], S.by[i], S.bz[i]);
-      L = v3(S.lx[i], S.ly[i], S.lz[i]);
-      meta = S.meta[i]; aux = S.aux[i]; pix = S.pix[i]; pattern = S.pattern[i];
+      const float4 A = S.a[i], B = S.b[i], Cc = S.c[i];
+      const uint4 D = S.d[i];
+      const V3 ro = v3(A.x, A.y, A.z), rd = v3(A.w, B.x, B.y);
+      time = P.has_motion ? S.time[i] : 0.0f;
+      beta = v3(B.z, B.w, Cc.x);
+      L = v3(Cc.y, Cc.z, Cc.w);
+      pattern = D.x; pix = D.y; meta = D.z; aux = D.w;
       const uint32_t n_rec = meta & 0xffffu;
       const int remaining = (int)(meta >> 16);
       const bool prev_valid = (aux & kPrevValid) != 0, prev_delta = (aux & kPrevDelta) != 0;
@@ -235,8 +282,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(Params P, PathSoA S, PathSoA N
       rec.front_face = ((hg >> 31) & 1u) != 0;
       rec.t = 0.0f; rec.normal = splat(0.0f); rec.p = splat(0.0f);
       if (has_hit) {
-        rec.t = H.t[i];
-        rec.normal = v3(H.nx[i], H.ny[i], H.nz[i]);
+        const float4 hh = H.h[i];
+        rec.t = hh.x;
+        rec.normal = v3(hh.y, hh.z, hh.w);
         rec.p = ro + rd * rec.t;  // ray.at(t), rt_world.rs:221
       }
       hit_p = rec.p;
@@ -247,9 +295,10 @@ __global__ __launch_bounds__(kBlock) void k_shade(Params P, PathSoA S, PathSoA N
         if (prev_delta) return 1.0f;
         for (uint32_t k = 0; k < P.n_lights; k++) {  // LightList::find_by_geom, light.rs:436-440
           if (P.lights[k].geom_id == geom) {
-            const V3 from = v3(S.px[i], S.py[i], S.pz[i]);
+            const float4 E = S.e[i];
+            const V3 from = v3(E.x, E.y, E.z);
             const float light_pdf = rmax(solid_angle_pdf(P.lights[k], from, rec.p) / (float)P.n_lights, 1e-6f);
-            return bounce_weight(P.strategy, S.ppdf[i], light_pdf);
+            return bounce_weight(P.strategy, E.w, light_pdf);
           }
         }
         return 1.0f;
@@ -290,7 +339,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(Params P, PathSoA S, PathSoA N
           // === 1. direct lighting by light sampling (tracer.rs:1394-1445) ===
           if (P.strategy != CRT_STRATEGY_BSDF && P.n_lights > 0) {
             float nee_s[4];
-            draw_sample4(new_domain(vdom, K_NEE), nee_s);
+            draw_sample4(new_domain(vdom, K_NEE), nee_s, sobol_tab);
             uint32_t li = (uint32_t)(nee_s[0] * (float)P.n_lights);  // LightList::pick, light.rs:421-429
             if (li > P.n_lights - 1) li = P.n_lights - 1;
             const CrtLight &light = P.lights[li];
@@ -317,7 +366,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(Params P, PathSoA S, PathSoA N
 
           // === 2. indirect lighting by BSDF sampling (tracer.rs:1459-1523) ===
           Scatter sample;
-          if (mat_scatter(mat, rd, rec, new_domain(vdom, K_BSDF), sample)) {
+          if (mat_scatter(mat, rd, rec, new_domain(vdom, K_BSDF), sample, sobol_tab)) {
             const V3 dir = normalize(sample.dir);
             const float cosine = sample.delta ? 1.0f : fabs_(dot(rec.normal, dir));
             const V3 factor = (sample.value * cosine) / sample.pdf;
@@ -346,59 +395,67 @@ __global__ __launch_bounds__(kBlock) void k_shade(Params P, PathSoA S, PathSoA N
     }
 
     // ---- wave-level compaction: survivors go to the other state buffer, finished paths to the film ----
-    const uint32_t j = wave_append(alive, &C->count[1 - cur]);
+    const uint32_t j = seg0 + seg_append(alive, &lds_ctr[0]);
     const uint32_t sl = aux & 0xffffu;
     const uint32_t film_idx = sl * P.n_pix + pix;
     if (alive) {
-      N.ox[j] = n_o.x; N.oy[j] = n_o.y; N.oz[j] = n_o.z; N.dx[j] = n_d.x; N.dy[j] = n_d.y; N.dz[j] = n_d.z;
-      N.time[j] = time;
-      N.bx[j] = beta.x; N.by[j] = beta.y; N.bz[j] = beta.z;
-      N.lx[j] = L.x; N.ly[j] = L.y; N.lz[j] = L.z;
-      N.px[j] = hit_p.x; N.py[j] = hit_p.y; N.pz[j] = hit_p.z; N.ppdf[j] = n_ppdf;
-      N.pattern[j] = pattern; N.pix[j] = pix;
-      N.meta[j] = ((meta & 0xffffu) + 1u) | (((meta >> 16) - 1u) << 16);
-      N.aux[j] = sl | kPrevValid | (n_delta ? kPrevDelta : 0u);
+      N.a[j] = make_float4(n_o.x, n_o.y, n_o.z, n_d.x);
+      N.b[j] = make_float4(n_d.y, n_d.z, beta.x, beta.y);
+      N.c[j] = make_float4(beta.z, L.x, L.y, L.z);
+      N.d[j] = make_uint4(pattern, pix, ((meta & 0xffffu) + 1u) | (((meta >> 16) - 1u) << 16),
+                          sl | kPrevValid | (n_delta ? kPrevDelta : 0u));
+      if (P.n_lights) N.e[j] = make_float4(hit_p.x, hit_p.y, hit_p.z, n_ppdf);
+      if (P.has_motion) N.time[j] = time;
     } else if (active) {
-      staging[film_idx] = L.x;
-      staging[(size_t)staging_plane + film_idx] = L.y;
-      staging[2 * (size_t)staging_plane + film_idx] = L.z;
+      staging[film_idx] = make_float4(L.x, L.y, L.z, 0.0f);
     }
-    const uint32_t q = wave_append(want_shadow, &C->n_shadow);
+    const uint32_t q = seg0 + seg_append(want_shadow, &lds_ctr[1]);
     if (want_shadow) {
-      Q.ox[q] = hit_p.x; Q.oy[q] = hit_p.y; Q.oz[q] = hit_p.z; Q.dx[q] = sh_d.x; Q.dy[q] = sh_d.y; Q.dz[q] = sh_d.z;
-      Q.tmax[q] = sh_tmax; Q.time[q] = time;
-      Q.cx[q] = sh_c.x; Q.cy[q] = sh_c.y; Q.cz[q] = sh_c.z;
-      Q.target[q] = alive ? j : (kFilmTarget | film_idx);
+      Q.a[q] = make_float4(hit_p.x, hit_p.y, hit_p.z, sh_tmax);
+      Q.b[q] = make_float4(sh_d.x, sh_d.y, sh_d.z, time);
+      Q.c[q] = make_float4(sh_c.x, sh_c.y, sh_c.z, __uint_as_float(alive ? j : (kFilmTarget | film_idx)));
     }
   }
-  add_stat(&C->stats[1], s_closest); add_stat(&C->stats[2], s_shadow); add_stat(&C->stats[3], s_vertices);
-  add_stat(&C->stats[4], s_rr_t); add_stat(&C->stats[5], s_rr_k); add_stat(&C->stats[6], s_esc);
-  add_stat(&C->stats[7], s_depth);
+  add_stat(&lds_ctr[2], s_closest); add_stat(&lds_ctr[3], s_shadow); add_stat(&lds_ctr[4], s_vertices);
+  add_stat(&lds_ctr[5], s_rr_t); add_stat(&lds_ctr[6], s_rr_k); add_stat(&lds_ctr[7], s_esc);
+  add_stat(&lds_ctr[8], s_depth);
+  __syncthreads();
+  if (threadIdx.x == 0) {  // publish this segment's queues for the next stages (same workgroup index there)
+    C->seg[1 - cur][blockIdx.x] = lds_ctr[0];
+    C->seg[2][blockIdx.x] = lds_ctr[1];
+    C->seg[cur][blockIdx.x] = 0;  // consumed: this buffer is the output of the next round
+  }
+  if (threadIdx.x >= 1 && threadIdx.x <= 7 && lds_ctr[threadIdx.x + 1])
+    atomicAdd(&C->stats[threadIdx.x], (unsigned long long)lds_ctr[threadIdx.x + 1]);
 }
 
 // ---- shadow: World::occluded (rt_world.rs:235-237) for the queue; unoccluded requests pay out ----
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_shadow(Params P, PathSoA N, ShadowSoA Q, Counters *C, float *staging,
-                                                   uint32_t staging_plane, CrtTravStats *tstats) {
+__global__ __launch_bounds__(kBlock, CRT_SHADOW_WAVES) void k_shadow(Params P, PathSoA N, ShadowSoA Q, Counters *C, float4 *staging,
+                                                   CrtTravStats *tstats) {
   __shared__ uint32_t stack[kStackLds * kBlock];
-  const uint32_t n = C->n_shadow;
+  const uint32_t n = C->seg[2][blockIdx.x];
+  const uint32_t seg0 = blockIdx.x * P.seg_cap;
   LaneStats st = {};
   uint32_t err = 0, done = 0;
-  for (uint32_t q = blockIdx.x * kBlock + threadIdx.x; q < n; q += gridDim.x * kBlock) {
+  for (uint32_t q = seg0 + threadIdx.x; q < seg0 + n; q += kBlock) {
+    const float4 A = Q.a[q], B = Q.b[q];
     Hit h;
-    const bool occ = traverse<true, STATS>(P.scene, Q.ox[q], Q.oy[q], Q.oz[q], Q.dx[q], Q.dy[q], Q.dz[q], Q.time[q],
-                                           CRT_MASK_SHADOW, 0.001f, Q.tmax[q], h, &stack[threadIdx.x], err, st);
+    const bool occ = traverse<true, STATS>(P.scene, A.x, A.y, A.z, B.x, B.y, B.z, B.w, CRT_MASK_SHADOW, 0.001f, A.w, h,
+                                           &stack[threadIdx.x], err, st);
     done++;
     if (occ) continue;
-    const uint32_t tg = Q.target[q];
-    const float cx = Q.cx[q], cy = Q.cy[q], cz = Q.cz[q];
+    const float4 Cc = Q.c[q];
+    const uint32_t tg = __float_as_uint(Cc.w);
     if (tg & kFilmTarget) {  // the path ended at this vertex: its radiance already sits in the staging plane
       const uint32_t f = tg & ~kFilmTarget;
-      staging[f] = staging[f] + cx;
-      staging[(size_t)staging_plane + f] = staging[(size_t)staging_plane + f] + cy;
-      staging[2 * (size_t)staging_plane + f] = staging[2 * (size_t)staging_plane + f] + cz;
-    } else {
-      N.lx[tg] = N.lx[tg] + cx; N.ly[tg] = N.ly[tg] + cy; N.lz[tg] = N.lz[tg] + cz;
+      float4 v = staging[f];
+      v.x = v.x + Cc.x; v.y = v.y + Cc.y; v.z = v.z + Cc.z;
+      staging[f] = v;
+    } else {  // beta.z | L.xyz
+      float4 v = N.c[tg];
+      v.y = v.y + Cc.x; v.z = v.z + Cc.y; v.w = v.w + Cc.z;
+      N.c[tg] = v;
     }
   }
   if (err) atomicOr(&C->err, err);
@@ -425,35 +482,26 @@ __global__ __launch_bounds__(kBlock) void k_shadow(Params P, PathSoA N, ShadowSo
   }
 }
 
-// Between bounces: the buffer just consumed becomes the next output; the shadow queue empties.
-__global__ void k_flip(Counters *C, int consumed) {
-  C->count[consumed] = 0;
-  C->n_shadow = 0;
-}
-
 // ---- resolve: sum += color, in sample order; weight_sum += wx*wy = 1 (tracer.rs:599-600) ----
-__global__ __launch_bounds__(kBlock) void k_resolve(const float *staging, uint32_t staging_plane, uint32_t n_pix,
-                                                    uint32_t n_samples, float *film /* 4 planes: r g b w */) {
+__global__ __launch_bounds__(kBlock) void k_resolve(const float4 *staging, uint32_t n_pix, uint32_t n_samples,
+                                                    float4 *film /* r, g, b sums and weight_sum */) {
   for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < n_pix; p += gridDim.x * kBlock) {
-    float r = film[p], g = film[(size_t)n_pix + p], b = film[2 * (size_t)n_pix + p], w = film[3 * (size_t)n_pix + p];
+    float4 acc = film[p];
     for (uint32_t s = 0; s < n_samples; s++) {
-      const size_t f = (size_t)s * n_pix + p;
-      r = r + staging[f];
-      g = g + staging[(size_t)staging_plane + f];
-      b = b + staging[2 * (size_t)staging_plane + f];
-      w = w + 1.0f;
+      const float4 v = staging[(size_t)s * n_pix + p];
+      acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z;
+      acc.w = acc.w + 1.0f;
     }
-    film[p] = r; film[(size_t)n_pix + p] = g; film[2 * (size_t)n_pix + p] = b; film[3 * (size_t)n_pix + p] = w;
+    film[p] = acc;
   }
 }
 
 // pixel = sum / weight_sum (tracer.rs:630-634); rgb interleaved per owned pixel.
-__global__ __launch_bounds__(kBlock) void k_film_out(const float *film, uint32_t n_pix, float *rgb) {
+__global__ __launch_bounds__(kBlock) void k_film_out(const float4 *film, uint32_t n_pix, float *rgb) {
   for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < n_pix; p += gridDim.x * kBlock) {
-    const float w = film[3 * (size_t)n_pix + p];
-    const float r = film[p], g = film[(size_t)n_pix + p], b = film[2 * (size_t)n_pix + p];
+    const float4 v = film[p];
     // weight_sum > 0 always holds for box/triangle (w = taken); the fallback arm divides by `taken` = w too.
-    rgb[3 * (size_t)p] = r / w; rgb[3 * (size_t)p + 1] = g / w; rgb[3 * (size_t)p + 2] = b / w;
+    rgb[3 * (size_t)p] = v.x / v.w; rgb[3 * (size_t)p + 1] = v.y / v.w; rgb[3 * (size_t)p + 2] = v.z / v.w;
   }
 }
 
@@ -473,8 +521,8 @@ struct Renderer {
   HitSoA H{};
   ShadowSoA Q{};
   Counters *C = nullptr;
-  float *staging = nullptr;
-  float *film = nullptr;
+  float4 *staging = nullptr;
+  float4 *film = nullptr;
   CrtMaterial *d_materials = nullptr;
   CrtLight *d_lights = nullptr;
   uint32_t *d_pixels = nullptr;
@@ -512,33 +560,27 @@ struct Renderer {
   int ensure_buffers(uint32_t n_samples) {
     if (n_samples <= cap_samples && blob) return CRT_OK;
     if (blob) { (void)hipFree(blob); blob = nullptr; }
-    const size_t cap = (size_t)P.n_pix * n_samples;
-    if (cap == 0 || cap >= (size_t)0x7fffffff) return CRT_ERR_BAD_ARG;
-    const size_t plane = (cap * 4 + 255) & ~size_t(255);
-    const size_t n_planes = 2 * 21 + 5 + 12 + 3;
-    blob_bytes = plane * n_planes;
+    const size_t total = (size_t)P.n_pix * n_samples;
+    const size_t seg = ((total + (size_t)grid * kBlock - 1) / ((size_t)grid * kBlock)) * kBlock;  // slots per segment: whole chunks
+    const size_t cap = seg * grid;
+    if (total == 0 || cap >= (size_t)0x7fffffff) return CRT_ERR_BAD_ARG;
+    P.seg_cap = (uint32_t)seg;
+    const size_t p16 = (cap * 16 + 255) & ~size_t(255), p4 = (cap * 4 + 255) & ~size_t(255);
+    // 2 x (a b c d e [16 B] + time [4 B]) + hit (16 + 4) + shadow 3 x 16 + staging 16
+    blob_bytes = 2 * (5 * p16 + p4) + (p16 + p4) + 3 * p16 + p16;
     if (!CRT_HIP_OK(hipMalloc(&blob, blob_bytes))) return CRT_ERR_NO_DEVICE;
-    size_t k = 0;
-    auto next = [&]() { return blob + plane * (k++); };
+    char *cur_p = blob;
+    auto take = [&](size_t bytes) { char *r = cur_p; cur_p += bytes; return r; };
     for (int b = 0; b < 2; b++) {
-      PathSoA &s = S[b];
-      float **fl[] = {&s.ox, &s.oy, &s.oz, &s.dx, &s.dy, &s.dz, &s.time, &s.bx, &s.by, &s.bz, &s.lx, &s.ly, &s.lz,
-                      &s.px, &s.py, &s.pz, &s.ppdf};
-      for (float **f : fl) *f = reinterpret_cast<float *>(next());
-      uint32_t **ul[] = {&s.pattern, &s.pix, &s.meta, &s.aux};
-      for (uint32_t **u : ul) *u = reinterpret_cast<uint32_t *>(next());
+      S[b].a = (float4 *)take(p16); S[b].b = (float4 *)take(p16); S[b].c = (float4 *)take(p16);
+      S[b].d = (uint4 *)take(p16); S[b].e = (float4 *)take(p16); S[b].time = (float *)take(p4);
     }
-    H.t = (float *)next(); H.nx = (float *)next(); H.ny = (float *)next(); H.nz = (float *)next();
-    H.geom = (uint32_t *)next();
-    float **ql[] = {&Q.ox, &Q.oy, &Q.oz, &Q.dx, &Q.dy, &Q.dz, &Q.tmax, &Q.time, &Q.cx, &Q.cy, &Q.cz};
-    for (float **f : ql) *f = reinterpret_cast<float *>(next());
-    Q.target = (uint32_t *)next();
-    staging = (float *)next(); (void)next(); (void)next();  // three contiguous planes
-    staging_plane = (uint32_t)(plane / 4);
+    H.h = (float4 *)take(p16); H.geom = (uint32_t *)take(p4);
+    Q.a = (float4 *)take(p16); Q.b = (float4 *)take(p16); Q.c = (float4 *)take(p16);
+    staging = (float4 *)take(p16);
     cap_samples = n_samples;
     return CRT_OK;
   }
-  uint32_t staging_plane = 0;
 
   template <class F>
   void timed(int cls, hipStream_t st, F &&launch) {
@@ -559,20 +601,23 @@ struct Renderer {
     last_stream = st;
     Params p = P;
     p.sample_begin = sample_begin;
+    {  // segment size for THIS batch size (buffers may be larger)
+      const size_t total = (size_t)P.n_pix * n_samples;
+      p.seg_cap = (uint32_t)(((total + (size_t)grid * kBlock - 1) / ((size_t)grid * kBlock)) * kBlock);
+    }
     timed(3, st, [&] { hipLaunchKernelGGL(k_generate, dim3(grid), dim3(kBlock), 0, st, p, S[0], C, sample_begin, n_samples); });
     int cur = 0;
     for (uint32_t it = 0; it <= P.max_depth; it++) {
-      if (d_tstats) timed(0, st, [&] { hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kBlock), 0, st, p, S[cur], H, C, cur, d_tstats); });
-      else timed(0, st, [&] { hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kBlock), 0, st, p, S[cur], H, C, cur, d_tstats); });
-      timed(1, st, [&] { hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, st, p, S[cur], S[1 - cur], H, Q, C, cur, staging, staging_plane); });
+      if (d_tstats) timed(0, st, [&] { hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kBlock), 0, st, p, S[cur], H, C, cur, it == 0 ? 1 : 0, d_tstats); });
+      else timed(0, st, [&] { hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kBlock), 0, st, p, S[cur], H, C, cur, it == 0 ? 1 : 0, d_tstats); });
+      timed(1, st, [&] { hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, st, p, S[cur], S[1 - cur], H, Q, C, cur, staging); });
       if (P.n_lights > 0 && P.strategy != CRT_STRATEGY_BSDF) {
-        if (d_tstats) timed(2, st, [&] { hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(kBlock), 0, st, p, S[1 - cur], Q, C, staging, staging_plane, d_tstats + 1); });
-        else timed(2, st, [&] { hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(kBlock), 0, st, p, S[1 - cur], Q, C, staging, staging_plane, d_tstats); });
+        if (d_tstats) timed(2, st, [&] { hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(kBlock), 0, st, p, S[1 - cur], Q, C, staging, d_tstats + 1); });
+        else timed(2, st, [&] { hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(kBlock), 0, st, p, S[1 - cur], Q, C, staging, d_tstats); });
       }
-      timed(3, st, [&] { hipLaunchKernelGGL(k_flip, dim3(1), dim3(1), 0, st, C, cur); });
       cur = 1 - cur;
     }
-    timed(3, st, [&] { hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(kBlock), 0, st, staging, staging_plane, P.n_pix, n_samples, film); });
+    timed(3, st, [&] { hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(kBlock), 0, st, staging, P.n_pix, n_samples, film); });
     return CRT_HIP_OK(hipGetLastError()) ? CRT_OK : CRT_ERR_NO_DEVICE;
   }
 };
@@ -663,7 +708,10 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
   hipDeviceProp_t prop;
   int dev = 0;
   (void)hipGetDevice(&dev);
-  if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) r.grid = prop.multiProcessorCount * 8;
+  int mult = 16;
+  if (const char *e = getenv("CRT_GRID_MULT")) mult = atoi(e) > 0 ? atoi(e) : 16;  // tuning knob (workgroups per CU)
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) r.grid = prop.multiProcessorCount * mult;
+  if (r.grid > kMaxGrid) r.grid = kMaxGrid;
   return R;
 }
 void crt_renderer_free(CrtRenderer *r) { delete r; }

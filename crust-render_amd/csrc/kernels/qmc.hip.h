@@ -58,17 +58,34 @@ __device__ __forceinline__ Sampler sampler_new(int x, int y, int frame, int inde
 __device__ __forceinline__ Sampler new_domain(Sampler s, int key) {
   return Sampler{pcg_hash(s.pattern + 0x9e3779b9u * ((uint32_t)key + 1u)), s.index};
 }
-__device__ __forceinline__ void draw_sample4(Sampler s, float out[4]) {
+// Byte-sliced Sobol matrices for dimensions 1..3, kept in LDS: entry [(d-1)*4 + k][v] is the XOR of the
+// direction numbers 8k..8k+7 selected by the bits of byte v, so a 32-bit matrix-vector product over GF(2) is
+// four table reads instead of a 32-step loop of dependent global loads. Same linear map, same bits.
+constexpr int kSobolLdsWords = 3 * 4 * 256;
+
+__device__ __forceinline__ void sobol_tables_init(uint32_t *tab /* LDS, kSobolLdsWords */) {
+  for (int e = threadIdx.x; e < kSobolLdsWords; e += blockDim.x) {
+    const int v = e & 255, k = (e >> 8) & 3, d = (e >> 10) + 1;
+    uint32_t x = 0;
+#pragma unroll
+    for (int b = 0; b < 8; b++)
+      if ((v >> b) & 1) x ^= kSobolDirs[d][8 * k + b];
+    tab[e] = x;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void draw_sample4(Sampler s, float out[4], const uint32_t *tab) {
   const uint32_t idx = owen(s.index, pcg_hash(s.pattern));
+  const uint32_t b0 = idx & 255u, b1 = (idx >> 8) & 255u, b2 = (idx >> 16) & 255u, b3 = idx >> 24;
 #pragma unroll
   for (int d = 0; d < 4; d++) {
-    uint32_t x = 0;
+    uint32_t x;
     if (d == 0) {
       x = __brev(idx);  // dimension 0's matrix is the identity on reversed bits
     } else {
-      uint32_t i = idx;
-      for (int b = 0; i; b++, i >>= 1)
-        if (i & 1u) x ^= kSobolDirs[d][b];
+      const uint32_t *t = tab + (d - 1) * 1024;
+      x = t[b0] ^ t[256 + b1] ^ t[512 + b2] ^ t[768 + b3];
     }
     x = owen(x, pcg_hash(s.pattern + (uint32_t)d + 1u));
     out[d] = unit_f32(x);

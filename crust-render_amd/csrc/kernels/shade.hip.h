@@ -513,14 +513,15 @@ __device__ __forceinline__ V3 to_world(const Frame3 &f, V3 l) { return f.t * l.x
 
 // Material::scatter_importance (material.rs:40-45): OpenPBR::scatter_resolved (openpbr.rs:1026-1136);
 // Emissive never scatters (emissive.rs:30-38).
-__device__ bool mat_scatter(const CrtMaterial &m, V3 ray_dir, const HitRec &rec, Sampler dom, Scatter &out) {
+__device__ bool mat_scatter(const CrtMaterial &m, V3 ray_dir, const HitRec &rec, Sampler dom, Scatter &out,
+                            const uint32_t *sobol_tab) {
   if (m.kind == CRT_MAT_EMISSIVE) return false;
   const Frame3 frame = frame_new(rec.normal);
   const V3 v_world = -normalize(ray_dir);
   const V3 v_local = to_local(frame, v_world);
   if (v_local.z <= 0.0f) return false;
   float s[4];
-  draw_sample4(dom, s);
+  draw_sample4(dom, s, sobol_tab);
   const LobePmf pmf = lobe_pmf(m);
   const int lobe = lobe_pick(pmf, s[0]);
   if (lobe == LOBE_TRANSMISSION) {

@@ -184,18 +184,31 @@ __device__ bool traverse(const DevScene &S, float ox, float oy, float oz, float 
 
   uint32_t spill[kStackSpill];
   Frame frames[kMaxLevels];
+  // Logical stack = memory slots [0, sp-1) plus `top` in a register (valid when sp > 0): a push spills the
+  // old top, a pop reloads the next one early, so the LDS latency of the reload hides behind the work on the
+  // entry just popped.
   int sp = 0;
-  auto push = [&](uint32_t x) {
-    if (sp < kStackLds) lds[sp * kBlock] = x;
-    else if (sp - kStackLds < kStackSpill) spill[sp - kStackLds] = x;
+  uint32_t top = kInvalid;
+  auto mem_store = [&](int slot, uint32_t x) {
+    if (slot < kStackLds) lds[slot * kBlock] = x;
+    else if (slot - kStackLds < kStackSpill) spill[slot - kStackLds] = x;
     else err |= 1u;
+  };
+  auto mem_load = [&](int slot) -> uint32_t {
+    if (slot < kStackLds) return lds[slot * kBlock];
+    if (slot - kStackLds < kStackSpill) return spill[slot - kStackLds];
+    return kLeafTag | kInvalid;  // only after an overflow (err already set): harmless empty leaf tag
+  };
+  auto push = [&](uint32_t x) {
+    if (sp > 0) mem_store(sp - 1, top);
+    top = x;
     sp++;
   };
   auto pop = [&]() -> uint32_t {
+    const uint32_t x = top;
     sp--;
-    if (sp < kStackLds) return lds[sp * kBlock];
-    if (sp - kStackLds < kStackSpill) return spill[sp - kStackLds];
-    return kLeafTag | kInvalid;  // only after an overflow (err already set): harmless empty leaf tag
+    if (sp > 0) top = mem_load(sp - 1);
+    return x;
   };
 
   RayCtx r;
@@ -221,6 +234,66 @@ __device__ bool traverse(const DevScene &S, float ox, float oy, float oz, float 
       tri_normal(S, bdefer, bu, bv, bnx, bny, bnz);
       bdefer = kInvalid;
     }
+  };
+
+  // ---- inner node: 4-wide slab test (bvh.rs:790-808); pushes the hit lanes ----
+  auto expand_node = [&](uint32_t e) {
+    if (STATS) st.nodes[level > 0 ? 1 : 0]++;
+    const WideNode *nd = &S.nodes[e];
+    const float4 *nb = reinterpret_cast<const float4 *>(nd);
+    const float4 mnx = nb[0], mny = nb[1], mnz = nb[2], mxx = nb[3], mxy = nb[4], mxz = nb[5];
+    const uint4 ch = *reinterpret_cast<const uint4 *>(nd->child);
+    const uint32_t flags = nd->flags;
+    const float lo_x[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, lo_y[4] = {mny.x, mny.y, mny.z, mny.w},
+                lo_z[4] = {mnz.x, mnz.y, mnz.z, mnz.w};
+    const float hi_x[4] = {mxx.x, mxx.y, mxx.z, mxx.w}, hi_y[4] = {mxy.x, mxy.y, mxy.z, mxy.w},
+                hi_z[4] = {mxz.x, mxz.y, mxz.z, mxz.w};
+    const uint32_t child[4] = {ch.x, ch.y, ch.z, ch.w};
+    const float bound = ANY ? t_max : closest;
+    float key[4];
+    uint32_t ent[4];
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+      const float t0x = (lo_x[l] - r.ox) * r.ix, t1x = (hi_x[l] - r.ox) * r.ix;
+      const float t0y = (lo_y[l] - r.oy) * r.iy, t1y = (hi_y[l] - r.oy) * r.iy;
+      const float t0z = (lo_z[l] - r.oz) * r.iz, t1z = (hi_z[l] - r.oz) * r.iz;
+      const float tn = fmaxf(fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z)), t_min);
+      const float tf = fminf(fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)), bound);
+      const bool on = (tn <= tf) && ((flags >> l) & 1u);
+      key[l] = tn;
+      ent[l] = on ? (child[l] | (((flags >> (4 + l)) & 1u) ? kLeafTag : 0u)) : kInvalid;  // kInvalid = lane off
+    }
+    if (ANY) {
+#pragma unroll
+      for (int l = 0; l < 4; l++)
+        if (ent[l] != kInvalid) push(ent[l]);
+      return;
+    }
+    // Stable insertion sort of the hit lanes by entry distance (bvh.rs:472-486). Lanes that are off
+    // sort as +inf keys and are skipped at push time; relative order of the hit lanes is the reference's.
+#pragma unroll
+    for (int l = 0; l < 4; l++)
+      if (ent[l] == kInvalid) key[l] = __builtin_inff();
+    // Off lanes must not overtake hit lanes with an infinite key: give them a strictly-last rank by
+    // sorting on (key, off) pairs — `off` breaks the tie.
+    auto after = [&](int a, int b) {  // does slot a sort strictly after slot b?
+      const bool offa = ent[a] == kInvalid, offb = ent[b] == kInvalid;
+      return (key[a] > key[b]) || (key[a] == key[b] && offa && !offb);
+    };
+    auto swp = [&](int a, int b) {
+      const float k = key[a]; key[a] = key[b]; key[b] = k;
+      const uint32_t x = ent[a]; ent[a] = ent[b]; ent[b] = x;
+    };
+    if (after(0, 1)) swp(0, 1);
+    if (after(1, 2)) { swp(1, 2); if (after(0, 1)) swp(0, 1); }
+    if (after(2, 3)) { swp(2, 3); if (after(1, 2)) { swp(1, 2); if (after(0, 1)) swp(0, 1); } }
+    // Inner lanes far to near, then leaf lanes far to near on top (bvh.rs:488-505, see header).
+#pragma unroll
+    for (int i = 3; i >= 0; i--)
+      if (ent[i] != kInvalid && !(ent[i] & kLeafTag)) push(ent[i]);
+#pragma unroll
+    for (int i = 3; i >= 0; i--)
+      if (ent[i] != kInvalid && (ent[i] & kLeafTag)) push(ent[i]);
   };
 
   for (;;) {
@@ -339,11 +412,21 @@ __device__ bool traverse(const DevScene &S, float ox, float oy, float oz, float 
       continue;
     }
 
-    const uint32_t e = pop();
+    // ---- node phase ("while-while"): expand inner nodes until a leaf entry surfaces or this tree's stack
+    // is empty. Keeping the lanes of a wave in the same phase is what keeps the SIMD lanes busy: a wave pays
+    // max-over-lanes node steps, then max-over-lanes leaf steps, instead of (node + leaf) per step.
+    uint32_t e = kInvalid;
+    bool have_leaf = false;
+    while ((uint32_t)sp > base) {
+      e = pop();
+      if (e & kLeafTag) { have_leaf = true; break; }
+      expand_node(e);
+    }
+    if (!have_leaf) continue;  // exhausted: the check at the top of the loop returns or finishes
     const int sl = level > 0 ? 1 : 0;
 
     // ---- leaf: 4-wide packets first, then the scalar list (bvh.rs:514-572) ----
-    if (e & kLeafTag) {
+    {
       const uint32_t li = e & ~kLeafTag;
       if (li == (kInvalid & ~kLeafTag)) continue;
       const Leaf lf = S.leaves[li];
@@ -436,63 +519,6 @@ __device__ bool traverse(const DevScene &S, float ox, float oy, float oz, float 
       continue;
     }
 
-    // ---- inner node: 4-wide slab test (bvh.rs:790-808) ----
-    if (STATS) st.nodes[sl]++;
-    const WideNode *nd = &S.nodes[e];
-    const float4 *nb = reinterpret_cast<const float4 *>(nd);
-    const float4 mnx = nb[0], mny = nb[1], mnz = nb[2], mxx = nb[3], mxy = nb[4], mxz = nb[5];
-    const uint4 ch = *reinterpret_cast<const uint4 *>(nd->child);
-    const uint32_t flags = nd->flags;
-    const float lo_x[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, lo_y[4] = {mny.x, mny.y, mny.z, mny.w},
-                lo_z[4] = {mnz.x, mnz.y, mnz.z, mnz.w};
-    const float hi_x[4] = {mxx.x, mxx.y, mxx.z, mxx.w}, hi_y[4] = {mxy.x, mxy.y, mxy.z, mxy.w},
-                hi_z[4] = {mxz.x, mxz.y, mxz.z, mxz.w};
-    const uint32_t child[4] = {ch.x, ch.y, ch.z, ch.w};
-    const float bound = ANY ? t_max : closest;
-    float key[4];
-    uint32_t ent[4];
-#pragma unroll
-    for (int l = 0; l < 4; l++) {
-      const float t0x = (lo_x[l] - r.ox) * r.ix, t1x = (hi_x[l] - r.ox) * r.ix;
-      const float t0y = (lo_y[l] - r.oy) * r.iy, t1y = (hi_y[l] - r.oy) * r.iy;
-      const float t0z = (lo_z[l] - r.oz) * r.iz, t1z = (hi_z[l] - r.oz) * r.iz;
-      const float tn = fmaxf(fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z)), t_min);
-      const float tf = fminf(fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)), bound);
-      const bool on = (tn <= tf) && ((flags >> l) & 1u);
-      key[l] = tn;
-      ent[l] = on ? (child[l] | (((flags >> (4 + l)) & 1u) ? kLeafTag : 0u)) : kInvalid;  // kInvalid = lane off
-    }
-    if (ANY) {
-#pragma unroll
-      for (int l = 0; l < 4; l++)
-        if (ent[l] != kInvalid) push(ent[l]);
-      continue;
-    }
-    // Stable insertion sort of the hit lanes by entry distance (bvh.rs:472-486). Lanes that are off
-    // sort as +inf keys and are skipped at push time; relative order of the hit lanes is the reference's.
-#pragma unroll
-    for (int l = 0; l < 4; l++)
-      if (ent[l] == kInvalid) key[l] = __builtin_inff();
-    // Off lanes must not overtake hit lanes with an infinite key: give them a strictly-last rank by
-    // sorting on (key, off) pairs — `off` breaks the tie.
-    auto after = [&](int a, int b) {  // does slot a sort strictly after slot b?
-      const bool offa = ent[a] == kInvalid, offb = ent[b] == kInvalid;
-      return (key[a] > key[b]) || (key[a] == key[b] && offa && !offb);
-    };
-    auto swp = [&](int a, int b) {
-      const float k = key[a]; key[a] = key[b]; key[b] = k;
-      const uint32_t x = ent[a]; ent[a] = ent[b]; ent[b] = x;
-    };
-    if (after(0, 1)) swp(0, 1);
-    if (after(1, 2)) { swp(1, 2); if (after(0, 1)) swp(0, 1); }
-    if (after(2, 3)) { swp(2, 3); if (after(1, 2)) { swp(1, 2); if (after(0, 1)) swp(0, 1); } }
-    // Inner lanes far to near, then leaf lanes far to near on top (bvh.rs:488-505, see header).
-#pragma unroll
-    for (int i = 3; i >= 0; i--)
-      if (ent[i] != kInvalid && !(ent[i] & kLeafTag)) push(ent[i]);
-#pragma unroll
-    for (int i = 3; i >= 0; i--)
-      if (ent[i] != kInvalid && (ent[i] & kLeafTag)) push(ent[i]);
   }
 
   if (ANY) return false;

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Summarises rocprofv3 --pmc passes (gpurun_out/pmc_<tag>_<n>/*/…_counter_collection.csv) per kernel.
+FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads
+(MI355X_MICROARCH.md §HBM), so the corrected read bytes are reported as 2x next to the raw figure."""
+import csv, glob, collections, json, sys, re
+
+tag = sys.argv[1]
+out = collections.defaultdict(lambda: collections.defaultdict(float))
+launches = collections.defaultdict(lambda: collections.defaultdict(int))
+for d in sorted(glob.glob(f"gpurun_out/pmc_{tag}_*/*/*_counter_collection.csv")):
+    for r in csv.DictReader(open(d)):
+        name = r["Kernel_Name"]
+        m = re.search(r"(k_\w+)(<\w+>)?", name)
+        k = (m.group(1) + (m.group(2) or "")) if m else name[:40]
+        out[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        launches[k][r["Counter_Name"]] += 1
+res = {}
+for k, c in out.items():
+    n = max(launches[k].values())
+    e = dict(launches=n, **{kk: vv for kk, vv in sorted(c.items())})
+    if "TCC_HIT_sum" in c:
+        e["l2_hit_rate"] = c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1)
+    if "FETCH_SIZE" in c:
+        e["hbm_read_bytes_raw"] = c["FETCH_SIZE"] * 1024
+        e["hbm_read_bytes_x2"] = c["FETCH_SIZE"] * 2048
+    if "WRITE_SIZE" in c:
+        e["hbm_write_bytes"] = c["WRITE_SIZE"] * 1024
+    if "SQ_WAVE_CYCLES" in c and c["SQ_WAVE_CYCLES"]:
+        e["valu_active_frac"] = c.get("SQ_ACTIVE_INST_VALU", 0) / c["SQ_WAVE_CYCLES"]
+        e["wait_any_frac"] = c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"]
+        e["wait_inst_frac"] = c.get("SQ_WAIT_INST_ANY", 0) / c["SQ_WAVE_CYCLES"]
+    res[k] = e
+print(json.dumps(res, indent=1))
