@@ -138,6 +138,7 @@ struct DevScene {
   const float *normals;  // 9 floats per smooth triangle
   uint32_t root;         // CRT_INVALID_ID when the scene is empty (bvh.rs:442-444)
   uint32_t has_packets;
+  uint32_t n_nodes;      // nodes are numbered breadth-first, top-level tree first (see Scene::ensure_device)
 };
 
 struct DeviceImage {

@@ -112,6 +112,18 @@ __device__ __forceinline__ float bounce_weight(int s, float bounce_pdf, float li
   }
 }
 
+__device__ __forceinline__ bool lds_take(bool want, uint32_t *next, uint32_t limit, uint32_t &idx) {
+  const unsigned long long mask = __ballot(want);
+  if (mask == 0) return false;
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll((long long)mask) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(next, (uint32_t)__popcll(mask));
+  base = __shfl(base, leader, 64);
+  idx = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+  return want && idx < limit;
+}
+
 // Segment-local append: every lane with `want` gets a unique slot of its workgroup's segment. The wave's
 // lanes are ranked with a ballot + popcount prefix; one LDS atomic per wave reserves the run.
 __device__ __forceinline__ uint32_t seg_append(bool want, uint32_t *lds_counter) {
@@ -193,28 +205,39 @@ template <bool STATS>
 __global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_extend(Params P, PathSoA S, HitSoA H, Counters *C, int cur, int first,
                                                    CrtTravStats *tstats) {
   __shared__ uint32_t stack[kStackLds * kBlock];
+  __shared__ __attribute__((aligned(16))) uint32_t lds_nodes[kLdsNodes * kLdsNodeStride];
   const uint32_t n = C->seg[cur][blockIdx.x];
+  if (n == 0) return;  // uniform per workgroup
+  __shared__ uint32_t next;
+  if (threadIdx.x == 0) next = 0;
+  const uint32_t n_lds = stage_nodes(P.scene, lds_nodes);  // ends with a barrier
   const uint32_t seg0 = blockIdx.x * P.seg_cap;
   LaneStats st = {};
   uint32_t err = 0, done = 0;
-  for (uint32_t i = seg0 + threadIdx.x; i < seg0 + n; i += kBlock) {
+  // every path of the first round is a camera ray, every later one an indirect ray (camera.rs:83, tracer.rs:1516-1519)
+  const uint32_t mask = first ? CRT_MASK_CAMERA : CRT_MASK_INDIRECT;
+  auto fetch = [&](bool want, RayIn &in) -> bool {
+    uint32_t k;
+    if (!lds_take(want, &next, n, k)) return false;
+    const uint32_t i = seg0 + k;
     const float4 A = S.a[i], B = S.b[i];
-    const float ox = A.x, oy = A.y, oz = A.z, dx = A.w, dy = B.x, dz = B.y;
-    const float time = P.has_motion ? S.time[i] : 0.0f;
-    // every path of the first round is a camera ray, every later one an indirect ray (camera.rs:83, tracer.rs:1516-1519)
-    const uint32_t mask = first ? CRT_MASK_CAMERA : CRT_MASK_INDIRECT;
-    Hit h;
-    const bool hit = traverse<false, STATS>(P.scene, ox, oy, oz, dx, dy, dz, time, mask, 0.001f, CRT_INF, h,
-                                            &stack[threadIdx.x], err, st);
+    in.ox = A.x; in.oy = A.y; in.oz = A.z; in.dx = A.w; in.dy = B.x; in.dz = B.y;
+    in.time = P.has_motion ? S.time[i] : 0.0f;
+    in.mask = mask; in.t_min = 0.001f; in.t_max = CRT_INF; in.slot = i;
+    return true;
+  };
+  auto emit = [&](uint32_t i, bool hit, const Hit &h) {
     if (hit) {
-      const bool front = dot3(dx, dy, dz, h.nx, h.ny, h.nz) < 0.0f;  // scene.rs:356-359
+      const float4 A = S.a[i], B = S.b[i];
+      const bool front = dot3(A.w, B.x, B.y, h.nx, h.ny, h.nz) < 0.0f;  // scene.rs:356-359
       H.h[i] = make_float4(h.t, front ? h.nx : -h.nx, front ? h.ny : -h.ny, front ? h.nz : -h.nz);
       H.geom[i] = h.geom | (front ? 0x80000000u : 0u);
     } else {
       H.geom[i] = kInvalid;
     }
     done++;
-  }
+  };
+  traverse_stream<false, STATS>(P.scene, &stack[threadIdx.x], lds_nodes, n_lds, err, st, fetch, emit);
   if (err) atomicOr(&C->err, err);
   if (STATS) {
     auto wave_sum = [](uint32_t v) { for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64); return v; };
@@ -434,17 +457,27 @@ template <bool STATS>
 __global__ __launch_bounds__(kBlock, CRT_SHADOW_WAVES) void k_shadow(Params P, PathSoA N, ShadowSoA Q, Counters *C, float4 *staging,
                                                    CrtTravStats *tstats) {
   __shared__ uint32_t stack[kStackLds * kBlock];
+  __shared__ __attribute__((aligned(16))) uint32_t lds_nodes[kLdsNodes * kLdsNodeStride];
   const uint32_t n = C->seg[2][blockIdx.x];
+  if (n == 0) return;  // uniform per workgroup
+  __shared__ uint32_t next;
+  if (threadIdx.x == 0) next = 0;
+  const uint32_t n_lds = stage_nodes(P.scene, lds_nodes);  // ends with a barrier
   const uint32_t seg0 = blockIdx.x * P.seg_cap;
   LaneStats st = {};
   uint32_t err = 0, done = 0;
-  for (uint32_t q = seg0 + threadIdx.x; q < seg0 + n; q += kBlock) {
+  auto fetch = [&](bool want, RayIn &in) -> bool {
+    uint32_t k;
+    if (!lds_take(want, &next, n, k)) return false;
+    const uint32_t q = seg0 + k;
     const float4 A = Q.a[q], B = Q.b[q];
-    Hit h;
-    const bool occ = traverse<true, STATS>(P.scene, A.x, A.y, A.z, B.x, B.y, B.z, B.w, CRT_MASK_SHADOW, 0.001f, A.w, h,
-                                           &stack[threadIdx.x], err, st);
+    in.ox = A.x; in.oy = A.y; in.oz = A.z; in.dx = B.x; in.dy = B.y; in.dz = B.z;
+    in.time = B.w; in.mask = CRT_MASK_SHADOW; in.t_min = 0.001f; in.t_max = A.w; in.slot = q;
+    return true;
+  };
+  auto emit = [&](uint32_t q, bool occ, const Hit &) {
     done++;
-    if (occ) continue;
+    if (occ) return;
     const float4 Cc = Q.c[q];
     const uint32_t tg = __float_as_uint(Cc.w);
     if (tg & kFilmTarget) {  // the path ended at this vertex: its radiance already sits in the staging plane
@@ -457,7 +490,8 @@ __global__ __launch_bounds__(kBlock, CRT_SHADOW_WAVES) void k_shadow(Params P, P
       v.y = v.y + Cc.x; v.z = v.z + Cc.y; v.w = v.w + Cc.z;
       N.c[tg] = v;
     }
-  }
+  };
+  traverse_stream<true, STATS>(P.scene, &stack[threadIdx.x], lds_nodes, n_lds, err, st, fetch, emit);
   if (err) atomicOr(&C->err, err);
   if (STATS) {
     auto wave_sum = [](uint32_t v) { for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64); return v; };

@@ -34,21 +34,53 @@ __device__ __forceinline__ void flush_stats(const LaneStats &st, CrtTravStats *o
   }
 }
 
+// Rays are dealt to workgroups in contiguous chunks; inside a workgroup the waves pull them from an LDS
+// counter as their lanes fall idle (persistent-wave scheduling, see traverse_stream).
+struct Chunk { size_t first, count; };
+__device__ __forceinline__ Chunk my_chunk(size_t n) {
+  const size_t per = (n + gridDim.x - 1) / gridDim.x;
+  const size_t first = (size_t)blockIdx.x * per;
+  return Chunk{first, first >= n ? 0 : (n - first < per ? n - first : per)};
+}
+__device__ __forceinline__ bool lds_take(bool want, uint32_t *next, uint32_t limit, uint32_t &idx) {
+  const unsigned long long mask = __ballot(want);
+  if (mask == 0) return false;
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll((long long)mask) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(next, (uint32_t)__popcll(mask));
+  base = __shfl(base, leader, 64);
+  idx = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+  return want && idx < limit;
+}
+
 template <bool STATS>
 __global__ __launch_bounds__(kBlock) void intersect_n_kernel(DevScene S, const CrtRay *__restrict__ rays, size_t n,
                                                             float t_min, float t_max, CrtRayHit *__restrict__ hits,
                                                             uint32_t *__restrict__ err_out, CrtTravStats *stats) {
   __shared__ uint32_t stack[kStackLds * kBlock];
+  __shared__ __attribute__((aligned(16))) uint32_t lds_nodes[kLdsNodes * kLdsNodeStride];
+  __shared__ uint32_t next;
+  const Chunk ck = my_chunk(n);
+  if (ck.count == 0) return;
+  if (threadIdx.x == 0) next = 0;
+  const uint32_t n_lds = stage_nodes(S, lds_nodes);  // ends with a barrier
   LaneStats st = {};
   uint32_t err = 0, done = 0;
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
-    const float4 *rp = reinterpret_cast<const float4 *>(rays + i);
+  auto fetch = [&](bool want, RayIn &in) -> bool {
+    uint32_t k;
+    if (!lds_take(want, &next, (uint32_t)ck.count, k)) return false;
+    const float4 *rp = reinterpret_cast<const float4 *>(rays + ck.first + k);
     const float4 o = rp[0], d = rp[1], tm = rp[2];
-    Hit h;
-    const bool hit = traverse<false, STATS>(S, o.x, o.y, o.z, d.x, d.y, d.z, tm.x, __float_as_uint(tm.y), t_min, t_max,
-                                            h, &stack[threadIdx.x], err, st);
+    in.ox = o.x; in.oy = o.y; in.oz = o.z; in.dx = d.x; in.dy = d.y; in.dz = d.z;
+    in.time = tm.x; in.mask = __float_as_uint(tm.y); in.t_min = t_min; in.t_max = t_max; in.slot = k;
+    return true;
+  };
+  auto emit = [&](uint32_t k, bool hit, const Hit &h) {
+    const size_t i = ck.first + k;
     CrtRayHit out;
     if (hit) {  // scene.rs:355-365
+      const float4 d = reinterpret_cast<const float4 *>(rays + i)[1];
       const bool front = dot3(d.x, d.y, d.z, h.nx, h.ny, h.nz) < 0.0f;
       out.t = h.t;
       out.normal[0] = front ? h.nx : -h.nx;
@@ -62,7 +94,8 @@ __global__ __launch_bounds__(kBlock) void intersect_n_kernel(DevScene S, const C
     }
     hits[i] = out;
     done++;
-  }
+  };
+  traverse_stream<false, STATS>(S, &stack[threadIdx.x], lds_nodes, n_lds, err, st, fetch, emit);
   if (err) atomicOr(err_out, err);
   if (STATS) flush_stats(st, stats, done);
 }
@@ -72,17 +105,28 @@ __global__ __launch_bounds__(kBlock) void occluded_n_kernel(DevScene S, const Cr
                                                            float t_min, float t_max, uint32_t *__restrict__ out,
                                                            uint32_t *__restrict__ err_out, CrtTravStats *stats) {
   __shared__ uint32_t stack[kStackLds * kBlock];
+  __shared__ __attribute__((aligned(16))) uint32_t lds_nodes[kLdsNodes * kLdsNodeStride];
+  __shared__ uint32_t next;
+  const Chunk ck = my_chunk(n);
+  if (ck.count == 0) return;
+  if (threadIdx.x == 0) next = 0;
+  const uint32_t n_lds = stage_nodes(S, lds_nodes);
   LaneStats st = {};
   uint32_t err = 0, done = 0;
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
-    const float4 *rp = reinterpret_cast<const float4 *>(rays + i);
+  auto fetch = [&](bool want, RayIn &in) -> bool {
+    uint32_t k;
+    if (!lds_take(want, &next, (uint32_t)ck.count, k)) return false;
+    const float4 *rp = reinterpret_cast<const float4 *>(rays + ck.first + k);
     const float4 o = rp[0], d = rp[1], tm = rp[2];
-    Hit h;
-    const bool occ = traverse<true, STATS>(S, o.x, o.y, o.z, d.x, d.y, d.z, tm.x, __float_as_uint(tm.y), t_min, t_max, h,
-                                           &stack[threadIdx.x], err, st);
-    out[i] = occ ? 1u : 0u;
+    in.ox = o.x; in.oy = o.y; in.oz = o.z; in.dx = d.x; in.dy = d.y; in.dz = d.z;
+    in.time = tm.x; in.mask = __float_as_uint(tm.y); in.t_min = t_min; in.t_max = t_max; in.slot = k;
+    return true;
+  };
+  auto emit = [&](uint32_t k, bool occ, const Hit &) {
+    out[ck.first + k] = occ ? 1u : 0u;
     done++;
-  }
+  };
+  traverse_stream<true, STATS>(S, &stack[threadIdx.x], lds_nodes, n_lds, err, st, fetch, emit);
   if (err) atomicOr(err_out, err);
   if (STATS) flush_stats(st, stats, done);
 }

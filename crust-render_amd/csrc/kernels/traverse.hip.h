@@ -31,8 +31,12 @@ namespace crt {
 namespace dev {
 
 constexpr int kBlock = 256;       // threads per workgroup (4 waves)
-constexpr int kStackLds = 24;     // stack entries per lane kept in LDS (24 KiB per workgroup)
-constexpr int kStackSpill = 232;  // further entries per lane in scratch: 3 * MAX_DEPTH + 4 fits twice over
+constexpr int kStackLds = 16;     // stack entries per lane kept in LDS (16 KiB per workgroup)
+constexpr int kStackSpill = 240;  // further entries per lane in scratch: 3 * MAX_DEPTH + 4 fits
+// Top of the tree staged in LDS: the first kLdsNodes nodes (breadth-first numbering) as 144-byte records
+// (128 + 16 pad: a 36-dword stride spreads the lanes' 16-byte reads over all banks). 36 KiB per workgroup.
+constexpr int kLdsNodes = 256;
+constexpr int kLdsNodeStride = 36;  // dwords
 constexpr int kMaxLevels = 8;     // instance nesting depth (usd_import.rs:60 MAX_INSTANCE_NESTING)
 constexpr uint32_t kLeafTag = 0x80000000u;
 constexpr uint32_t kInvalid = 0xFFFFFFFFu;
@@ -171,16 +175,43 @@ __device__ __forceinline__ void motion_w2l(const DevInstance &in, float time, fl
   w2l[9] = -rx; w2l[10] = -ry; w2l[11] = -rz;
 }
 
+// Cooperative copy of the top-of-tree window into LDS; returns the number of nodes staged. Ends with a barrier.
+__device__ __forceinline__ uint32_t stage_nodes(const DevScene &S, uint32_t *lds_nodes) {
+  const uint32_t n = S.n_nodes < (uint32_t)kLdsNodes ? S.n_nodes : (uint32_t)kLdsNodes;
+  for (uint32_t w = threadIdx.x; w < n * 8u; w += blockDim.x) {  // 8 x 16 bytes per node
+    const uint32_t node = w >> 3, part = w & 7u;
+    const float4 v = reinterpret_cast<const float4 *>(S.nodes + node)[part];
+    *reinterpret_cast<float4 *>(lds_nodes + (size_t)node * kLdsNodeStride + part * 4) = v;
+  }
+  __syncthreads();
+  return n;
+}
+
 struct Frame {
   float ox, oy, oz, dx, dy, dz;
   uint32_t cursor, cend, base, inst, geom, has_packets;
 };
 
-template <bool ANY, bool STATS>
-__device__ bool traverse(const DevScene &S, float ox, float oy, float oz, float dx, float dy, float dz, float time,
-                         uint32_t rmask, float t_min, float t_max, Hit &hit, uint32_t *lds /* &stack[tid] */,
-                         uint32_t &err, LaneStats &st) {
-  if (S.root == kInvalid) return false;  // bvh.rs:442-444
+// One ray handed to a lane by the fetch callback of traverse_stream.
+struct RayIn {
+  float ox, oy, oz, dx, dy, dz, time, t_min, t_max;
+  uint32_t mask;
+  uint32_t slot;  // caller's tag, passed back to emit
+};
+
+constexpr int kRefillIdle = 24;  // refill a wave once this many of its 64 lanes have no ray
+
+// Persistent-wave traversal: a wave keeps pulling rays until its source is dry. Whenever enough lanes have
+// finished, they fetch new rays while the others keep their traversal state, so one long ray does not hold 63
+// idle lanes hostage (incoherent secondary rays finish after very different numbers of steps).
+//   fetch(want, ray) -> bool : called by the whole wave; lanes with want==true may receive a ray
+//   emit(slot, hit?, Hit)    : called by a lane whose ray is finished (ANY: hit? means occluded)
+template <bool ANY, bool STATS, class Fetch, class Emit>
+__device__ void traverse_stream(const DevScene &S, uint32_t *lds /* &stack[tid] */,
+                                const uint32_t *lds_nodes /* staged window */, uint32_t n_lds, uint32_t &err,
+                                LaneStats &st, Fetch fetch, Emit emit) {
+  float time = 0.0f, t_min = 0.0f, t_max = 0.0f;
+  uint32_t rmask = 0, slot = 0;
 
   uint32_t spill[kStackSpill];
   Frame frames[kMaxLevels];
@@ -211,19 +242,26 @@ __device__ bool traverse(const DevScene &S, float ox, float oy, float oz, float 
     return x;
   };
 
-  RayCtx r;
-  r.ox = ox; r.oy = oy; r.oz = oz; r.dx = dx; r.dy = dy; r.dz = dz;
-  setup_ray(r, S.has_packets != 0);
+  RayCtx r = {};
   uint32_t cur_has_packets = S.has_packets;
-
-  float closest = t_max;
+  float closest = 0.0f;
   float bt = 0.0f, bu = 0.0f, bv = 0.0f, bnx = 0.0f, bny = 0.0f, bnz = 0.0f;
   uint32_t bgeom = kInvalid, bprim = kInvalid, bdefer = kInvalid;  // bdefer: triangle whose normal is pending
   uint32_t found = 0;  // bit L: level L holds a hit
   int level = 0;
   uint32_t base = 0, cursor = 0, cend = 0;
-  if (STATS) st.queries[0]++;
-  push(S.root);
+  auto begin = [&](const RayIn &in) {
+    r.ox = in.ox; r.oy = in.oy; r.oz = in.oz; r.dx = in.dx; r.dy = in.dy; r.dz = in.dz;
+    time = in.time; t_min = in.t_min; t_max = in.t_max; rmask = in.mask; slot = in.slot;
+    cur_has_packets = S.has_packets;
+    setup_ray(r, cur_has_packets != 0);
+    closest = t_max;
+    bgeom = kInvalid; bprim = kInvalid; bdefer = kInvalid;
+    found = 0; level = 0; base = 0; cursor = 0; cend = 0;
+    sp = 0; top = kInvalid;
+    if (STATS) st.queries[0]++;
+    if (S.root != kInvalid) push(S.root);  // an empty scene finishes at once (bvh.rs:442-444)
+  };
   // A triangle hit keeps only its primitive index until its tree is finished; ids and the normal are
   // derived once, here (prim.rs:76-95).
   auto finalize = [&]() {
@@ -239,11 +277,21 @@ __device__ bool traverse(const DevScene &S, float ox, float oy, float oz, float 
   // ---- inner node: 4-wide slab test (bvh.rs:790-808); pushes the hit lanes ----
   auto expand_node = [&](uint32_t e) {
     if (STATS) st.nodes[level > 0 ? 1 : 0]++;
-    const WideNode *nd = &S.nodes[e];
-    const float4 *nb = reinterpret_cast<const float4 *>(nd);
-    const float4 mnx = nb[0], mny = nb[1], mnz = nb[2], mxx = nb[3], mxy = nb[4], mxz = nb[5];
-    const uint4 ch = *reinterpret_cast<const uint4 *>(nd->child);
-    const uint32_t flags = nd->flags;
+    float4 mnx, mny, mnz, mxx, mxy, mxz;
+    uint4 ch;
+    uint32_t flags;
+    if (e < n_lds) {  // top of the tree: LDS (ds_read_b128), no trip through the vector memory pipeline
+      const float4 *nb = reinterpret_cast<const float4 *>(lds_nodes + (size_t)e * kLdsNodeStride);
+      mnx = nb[0]; mny = nb[1]; mnz = nb[2]; mxx = nb[3]; mxy = nb[4]; mxz = nb[5];
+      ch = *reinterpret_cast<const uint4 *>(nb + 6);
+      flags = lds_nodes[(size_t)e * kLdsNodeStride + 28];
+    } else {
+      const WideNode *nd = &S.nodes[e];
+      const float4 *nb = reinterpret_cast<const float4 *>(nd);
+      mnx = nb[0]; mny = nb[1]; mnz = nb[2]; mxx = nb[3]; mxy = nb[4]; mxz = nb[5];
+      ch = *reinterpret_cast<const uint4 *>(nd->child);
+      flags = nd->flags;
+    }
     const float lo_x[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, lo_y[4] = {mny.x, mny.y, mny.z, mny.w},
                 lo_z[4] = {mnz.x, mnz.y, mnz.z, mnz.w};
     const float hi_x[4] = {mxx.x, mxx.y, mxx.z, mxx.w}, hi_y[4] = {mxy.x, mxy.y, mxy.z, mxy.w},
@@ -296,13 +344,18 @@ __device__ bool traverse(const DevScene &S, float ox, float oy, float oz, float 
       if (ent[i] != kInvalid && (ent[i] & kLeafTag)) push(ent[i]);
   };
 
-  for (;;) {
+  // One scheduling step of the lane's ray: 0 = keep going, 1 = finished; ANY only: 2..5 = occluded, one code
+  // per kind of occluder. The codes are deliberately distinct: with four identical `return 2` sites hipcc
+  // (ROCm 7.2, gfx950) merged the exits and the occluded kernels reported 210 of 4096 missing rays of the
+  // `mixed` test scene as occluded; distinct exit values keep the exits apart (tests/test_gpu_traverse.py
+  // ::test_intersect_occluded_match_oracle_bitwise[mixed] is the regression test).
+  auto step = [&]() -> int {
     // ---- continue a leaf's one-at-a-time primitives (bvh.rs:564-570 / :646-651) ----
     if (cursor < cend) {
       const uint32_t pi = S.indices[cursor++];
       const DevPrim *p = &S.prims[pi];
       const uint4 hd = *reinterpret_cast<const uint4 *>(p);  // kind, geom_id, prim_id, mask
-      if ((rmask & hd.w) == 0) continue;                     // prim.rs:52-54
+      if ((rmask & hd.w) == 0) return 0;                     // prim.rs:52-54
       if (hd.x == PRIM_SPHERE) {                             // prim.rs:133-161
         const float4 s = *reinterpret_cast<const float4 *>(p->d);
         const float ocx = r.ox - s.x, ocy = r.oy - s.y, ocz = r.oz - s.z;
@@ -310,14 +363,14 @@ __device__ bool traverse(const DevScene &S, float ox, float oy, float oz, float 
         const float half_b = dot3(ocx, ocy, ocz, r.dx, r.dy, r.dz);
         const float c = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - s.w * s.w;
         const float disc = half_b * half_b - a * c;
-        if (disc < 0.0f) continue;
+        if (disc < 0.0f) return 0;
         const float sqrt_d = sqrtf(disc);
         float root = (-half_b - sqrt_d) / a;
         if (root <= t_min || root >= closest) {
           root = (-half_b + sqrt_d) / a;
-          if (root <= t_min || root >= closest) continue;
+          if (root <= t_min || root >= closest) return 0;
         }
-        if (ANY) return true;
+        if (ANY) return 2;  // occluded by a sphere
         closest = root;
         bt = root; bu = 0.0f; bv = 0.0f;
         bnx = ((r.ox + root * r.dx) - s.x) / s.w;
@@ -327,7 +380,7 @@ __device__ bool traverse(const DevScene &S, float ox, float oy, float oz, float 
         found |= 1u << level;
         if (STATS) st.accepted++;
       } else if (hd.x == PRIM_INSTANCE) {  // prim.rs:345-378
-        if (level + 1 >= kMaxLevels) { err |= 2u; continue; }
+        if (level + 1 >= kMaxLevels) { err |= 2u; return 0; }
         const DevInstance *in = &S.instances[__float_as_uint(p->d[0])];
         float w2l[12];
         if (in->has_end && time > 0.0f) motion_w2l(*in, time, w2l);
@@ -361,23 +414,23 @@ __device__ bool traverse(const DevScene &S, float ox, float oy, float oz, float 
         float t, u, v;
         RayCtx rr = r;
         if (!cur_has_packets) setup_ray(rr, true);
-        if (!tri_scalar(rr, p->d, t_min, closest, t, u, v)) continue;
-        if (ANY) return true;
+        if (!tri_scalar(rr, p->d, t_min, closest, t, u, v)) return 0;
+        if (ANY) return 3;  // occluded by a scalar-list triangle
         const float e1x = p->d[3] - p->d[0], e1y = p->d[4] - p->d[1], e1z = p->d[5] - p->d[2];
         const float e2x = p->d[6] - p->d[0], e2y = p->d[7] - p->d[1], e2z = p->d[8] - p->d[2];
         const bool flat = (e1y * e2z - e2y * e1z) == 0.0f && (e1z * e2x - e2z * e1x) == 0.0f &&
                           (e1x * e2y - e2x * e1y) == 0.0f;
-        if (flat && __float_as_uint(p->d[9]) == kInvalid) continue;
+        if (flat && __float_as_uint(p->d[9]) == kInvalid) return 0;
         closest = t; bt = t; bu = u; bv = v; bdefer = pi;
         found |= 1u << level;
         if (STATS) st.accepted++;
       }
-      continue;
+      return 0;
     }
 
     // ---- this tree is exhausted ----
     if ((uint32_t)sp == base) {
-      if (level == 0) break;
+      if (level == 0) return 1;
       const bool inner_found = (found >> level) & 1u;
       level--;
       const Frame &f = frames[level];
@@ -409,7 +462,7 @@ __device__ bool traverse(const DevScene &S, float ox, float oy, float oz, float 
       cursor = f.cursor; cend = f.cend; base = f.base;
       cur_has_packets = f.has_packets;
       setup_ray(r, cur_has_packets != 0);
-      continue;
+      return 0;
     }
 
     // ---- node phase ("while-while"): expand inner nodes until a leaf entry surfaces or this tree's stack
@@ -422,13 +475,13 @@ __device__ bool traverse(const DevScene &S, float ox, float oy, float oz, float 
       if (e & kLeafTag) { have_leaf = true; break; }
       expand_node(e);
     }
-    if (!have_leaf) continue;  // exhausted: the check at the top of the loop returns or finishes
+    if (!have_leaf) return 0;  // exhausted: the check at the top of the loop returns or finishes
     const int sl = level > 0 ? 1 : 0;
 
     // ---- leaf: 4-wide packets first, then the scalar list (bvh.rs:514-572) ----
     {
       const uint32_t li = e & ~kLeafTag;
-      if (li == (kInvalid & ~kLeafTag)) continue;
+      if (li == (kInvalid & ~kLeafTag)) return 0;
       const Leaf lf = S.leaves[li];
       if (STATS) { st.leaves[sl]++; st.packets[sl] += lf.pkt_count; st.prims[sl] += lf.idx_count; }
       for (uint32_t k = 0; k < lf.pkt_count; k++) {
@@ -484,7 +537,7 @@ __device__ bool traverse(const DevScene &S, float ox, float oy, float oz, float 
           hv[l] = e2 * inv_det;
         }
         if (ANY) {
-          if (hits) return true;
+          if (hits) return 4;  // occluded by a packet lane
         } else {
 #pragma unroll
           for (int l = 0; l < 4; l++) {  // bvh.rs:533-550
@@ -506,7 +559,7 @@ __device__ bool traverse(const DevScene &S, float ox, float oy, float oz, float 
             if ((rmask & p->mask) == 0) continue;
             float t, u, v;
             if (!tri_scalar(r, p->d, t_min, closest, t, u, v)) continue;
-            if (ANY) return true;
+            if (ANY) return 5;  // occluded by an on-edge (f64 fallback) lane
             if (!((pk->normal_ok >> l) & 1u)) continue;
             closest = t; bt = t; bu = u; bv = v; bdefer = pi;
             found |= 1u << level;
@@ -516,16 +569,44 @@ __device__ bool traverse(const DevScene &S, float ox, float oy, float oz, float 
       }
       cursor = lf.idx_first;
       cend = lf.idx_first + lf.idx_count;
-      continue;
+      return 0;
     }
 
-  }
+    return 0;
+  };
 
-  if (ANY) return false;
-  if (!(found & 1u)) return false;
-  finalize();
-  hit.t = bt; hit.u = bu; hit.v = bv; hit.nx = bnx; hit.ny = bny; hit.nz = bnz; hit.geom = bgeom; hit.prim = bprim;
-  return true;
+  bool active = false;
+  bool more = true;  // wave-uniform: the source may still hold rays
+  for (;;) {
+    const unsigned long long act = __ballot(active);
+    if (more && (act == 0 || 64 - __popcll(act) >= kRefillIdle)) {
+      RayIn in;
+      if (fetch(!active, in)) {
+        begin(in);
+        active = true;
+      }
+      if (__ballot(!active)) more = false;  // a lane asked and got nothing: the source is dry
+    }
+    if (!__ballot(active)) break;
+    if (active) {
+      const int rc = step();
+      if (rc) {
+        Hit hit;
+        bool is_hit;
+        if (ANY) {
+          is_hit = rc >= 2;
+        } else {
+          is_hit = (found & 1u) != 0;
+          if (is_hit) {
+            finalize();
+            hit.t = bt; hit.u = bu; hit.v = bv; hit.nx = bnx; hit.ny = bny; hit.nz = bnz; hit.geom = bgeom; hit.prim = bprim;
+          }
+        }
+        emit(slot, is_hit, hit);
+        active = false;
+      }
+    }
+  }
 }
 
 }  // namespace dev

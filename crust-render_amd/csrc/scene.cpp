@@ -254,6 +254,43 @@ int Scene::ensure_device() {
   if (!device_ok()) return CRT_ERR_NO_DEVICE;
   Flat f;
   Flat::Placed me = place(f, *this);
+  // Renumber the nodes breadth-first, the queried scene's tree first, then the instanced trees: the first K
+  // nodes of the array are then the top levels of the top-level tree — the window the kernels stage in LDS.
+  // Node numbers are opaque to traversal (children are visited by lane order and distance), so results and
+  // visit order do not change.
+  if (!f.nodes.empty()) {
+    std::vector<uint32_t> roots;
+    if (me.root != CRT_INVALID_ID) roots.push_back(me.root);
+    for (const DevInstance &in : f.instances)
+      if (in.root != CRT_INVALID_ID) roots.push_back(in.root);
+    std::vector<uint32_t> new_idx(f.nodes.size(), CRT_INVALID_ID), order;
+    order.reserve(f.nodes.size());
+    for (uint32_t r : roots) {
+      if (new_idx[r] != CRT_INVALID_ID) continue;
+      size_t head = order.size();
+      new_idx[r] = uint32_t(order.size());
+      order.push_back(r);
+      while (head < order.size()) {
+        const WideNode &n = f.nodes[order[head++]];
+        for (int l = 0; l < 4; l++) {
+          if (!(n.flags & (1u << l)) || (n.flags & (1u << (4 + l)))) continue;
+          const uint32_t c = n.child[l];
+          if (new_idx[c] == CRT_INVALID_ID) { new_idx[c] = uint32_t(order.size()); order.push_back(c); }
+        }
+      }
+    }
+    std::vector<WideNode> renum(order.size());
+    for (size_t k = 0; k < order.size(); k++) {
+      WideNode n = f.nodes[order[k]];
+      for (int l = 0; l < 4; l++)
+        if ((n.flags & (1u << l)) && !(n.flags & (1u << (4 + l)))) n.child[l] = new_idx[n.child[l]];
+      renum[k] = n;
+    }
+    f.nodes.swap(renum);
+    for (DevInstance &in : f.instances)
+      if (in.root != CRT_INVALID_ID) in.root = new_idx[in.root];
+    if (me.root != CRT_INVALID_ID) me.root = new_idx[me.root];
+  }
   auto img = std::make_unique<DeviceImage>();
   const size_t sz[7] = {f.nodes.size() * sizeof(WideNode), f.leaves.size() * sizeof(Leaf),
                         f.packets.size() * sizeof(Tri4),   f.indices.size() * sizeof(uint32_t),
@@ -282,6 +319,7 @@ int Scene::ensure_device() {
   img->view.normals = reinterpret_cast<const float *>(base + off[6]);
   img->view.root = me.root;
   img->view.has_packets = me.has_packets;
+  img->view.n_nodes = uint32_t(f.nodes.size());
   dev = std::move(img);
   return CRT_OK;
 }
