@@ -46,7 +46,8 @@ def main():
     ap.add_argument("--scene", default="cornellbox")
     ap.add_argument("--depth", type=int, default=None, help="override max depth (default: the scene's, 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=2, help="spp of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-spp", type=int, default=128, help="spp of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = this box's share: min(affinity, 16 per GPU))")
     args = ap.parse_args()
 
     import numpy as np
@@ -96,11 +97,7 @@ def main():
         r.render_samples(k * spp_step, spp_step, stream)
     r.film_to(d_rgb, stream)
     if dist is not None:  # the one data-path collective: gather the tile buffers (padded to the largest shard)
-        n_max = (n_pix_total // 256 // world + 1) * 256
-        send = torch.zeros(n_max * 3, dtype=torch.float32, device="cuda")
-        send[: r.n_pix * 3] = d_rgb
-        recv = torch.empty(world * n_max * 3, dtype=torch.float32, device="cuda")
-        dist.all_gather_into_tensor(recv, send)
+        frame = crt.shard.gather_frame(d_rgb.reshape(-1, 3), args.width, args.height, rank, world, dist)
     barrier()
     elapsed = time.perf_counter() - t0
     st = r.stats()
@@ -200,7 +197,11 @@ def _cpu_baseline(crt, desc, args):
     tracer.rs:424-459) on a bounded sample of the same workload: the full frame at --cpu-spp samples."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import ora_world
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = os.cpu_count() or 1
+    cores = args.cpu_threads if args.cpu_threads > 0 else min(avail, 16)  # a 1-GPU box's CPU share is 16 cores
     o = ora_world.OracleRenderer(desc, crt.usda, max_depth=args.depth, forward=0)
     t0 = time.perf_counter()
     _, st = o.render(args.cpu_spp, threads=cores)

@@ -146,7 +146,7 @@ ABI_SYMBOLS = [
     "crt_attach_instance", "crt_attach_empty", "crt_set_triangles", "crt_set_sphere", "crt_set_instance", "crt_commit",
     "crt_scene_retain", "crt_scene_release", "crt_scene_bounds", "crt_scene_geometry_count", "crt_scene_has_motion",
     "crt_scene_primitive_count", "crt_scene_primitive_breakdown", "crt_scene_memory_footprint", "crt_scene_tree",
-    "crt_intersect1", "crt_occluded1", "crt_intersect_n", "crt_occluded_n", "crt_intersect_n_stats",
+    "crt_shard_pixels", "crt_intersect1", "crt_occluded1", "crt_intersect_n", "crt_occluded_n", "crt_intersect_n_stats",
     "crt_occluded_n_stats", "crt_material_default", "crt_camera_new", "crt_renderer_new", "crt_renderer_free",
     "crt_renderer_pixel_count", "crt_renderer_pixel_indices", "crt_render_samples", "crt_film_resolve",
     "crt_film_read", "crt_film_clear", "crt_render_stats", "crt_renderer_profile", "crt_renderer_profile_read",
@@ -205,6 +205,8 @@ def lib():
     L.crt_intersect_n_stats.argtypes = [vp, vp, C.c_size_t, C.c_float, C.c_float, vp, vp, C.POINTER(CrtTravStats)]
     L.crt_occluded_n_stats.argtypes = [vp, vp, C.c_size_t, C.c_float, C.c_float, vp, vp, C.POINTER(CrtTravStats)]
     L.crt_material_default.argtypes = [C.POINTER(CrtMaterial)]
+    L.crt_shard_pixels.restype = C.c_size_t
+    L.crt_shard_pixels.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, up]
     if hasattr(L, "crt_renderer_new"):
         L.crt_camera_new.argtypes = [C.POINTER(CrtCamera), fp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float]
         L.crt_renderer_new.restype = vp
@@ -624,3 +626,4 @@ def load_usda(path, width=None, height=None, max_depth=None, rank=0, world=1):
     return r, desc
 
 from . import usda  # noqa: E402,F401  (the minimal USDA reader)
+from . import shard  # noqa: E402,F401  (pixel-tile sharding + the tile gather)

@@ -291,6 +291,22 @@ int crt_occluded1(CrtScene *s, const CrtRay *ray, float t_min, float t_max) {
   return h ? 1 : 0;
 }
 
+size_t crt_shard_pixels(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, uint32_t *out) {
+  if (world == 0 || rank >= world) return 0;
+  const uint32_t tx = (width + 15) / 16, ty = (height + 15) / 16;
+  size_t n = 0;
+  for (uint32_t t = 0; t < tx * ty; t++) {
+    if (t % world != rank) continue;
+    const uint32_t x0 = (t % tx) * 16, y0 = (t / tx) * 16;
+    for (uint32_t y = y0; y < y0 + 16 && y < height; y++)
+      for (uint32_t x = x0; x < x0 + 16 && x < width; x++) {
+        if (out) out[n] = y * width + x;
+        n++;
+      }
+  }
+  return n;
+}
+
 void crt_material_default(CrtMaterial *m) {  // openpbr.rs:130-173
   if (!m) return;
   std::memset(m, 0, sizeof *m);

@@ -39,7 +39,7 @@ namespace {
 #define CRT_EXTEND_WAVES 3
 #endif
 #ifndef CRT_SHADE_WAVES
-#define CRT_SHADE_WAVES 2
+#define CRT_SHADE_WAVES 3
 #endif
 #ifndef CRT_SHADOW_WAVES
 #define CRT_SHADOW_WAVES 4
@@ -716,13 +716,8 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
   P.filter_radius = settings->filter_radius;
   P.has_motion = scene->p->has_motion ? 1u : 0u;
   // Pixel-tile shard: 16x16 tiles (tracer.rs:424, :1671-1686) dealt round-robin over the ranks.
-  const uint32_t tx = (P.width + 15) / 16, ty = (P.height + 15) / 16;
-  for (uint32_t t = 0; t < tx * ty; t++) {
-    if (t % tile_world != tile_rank) continue;
-    const uint32_t x0 = (t % tx) * 16, y0 = (t / tx) * 16;
-    for (uint32_t y = y0; y < y0 + 16 && y < P.height; y++)
-      for (uint32_t x = x0; x < x0 + 16 && x < P.width; x++) r.pixels.push_back(y * P.width + x);
-  }
+  r.pixels.resize(crt_shard_pixels(P.width, P.height, tile_rank, tile_world, nullptr));
+  crt_shard_pixels(P.width, P.height, tile_rank, tile_world, r.pixels.data());
   P.n_pix = (uint32_t)r.pixels.size();
   bool ok = P.n_pix > 0;
   ok = ok && CRT_HIP_OK(hipMalloc(&r.C, sizeof(Counters))) && CRT_HIP_OK(hipMemset(r.C, 0, sizeof(Counters)));

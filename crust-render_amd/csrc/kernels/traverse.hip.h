@@ -199,7 +199,10 @@ struct RayIn {
   uint32_t slot;  // caller's tag, passed back to emit
 };
 
-constexpr int kRefillIdle = 24;  // refill a wave once this many of its 64 lanes have no ray
+#ifndef CRT_REFILL
+#define CRT_REFILL 32
+#endif
+constexpr int kRefillIdle = CRT_REFILL;  // refill a wave once this many of its 64 lanes have no ray
 
 // Persistent-wave traversal: a wave keeps pulling rays until its source is dry. Whenever enough lanes have
 // finished, they fetch new rays while the others keep their traversal state, so one long ray does not hold 63

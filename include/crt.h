@@ -194,6 +194,11 @@ typedef struct CrtRayStats {
   uint64_t camera_rays, closest_hit, shadow_rays, vertices, rr_tested, rr_killed, ended_escaped, ended_depth;
 } CrtRayStats;
 
+/* Pixel-tile sharding (host-only, no device needed): the frame's 16x16 tiles (tracer.rs:424, :1671-1686) are
+ * dealt round-robin to `world` ranks; returns how many pixels `rank` owns and, if out != NULL, their linear
+ * buffer indices j*width+i in the order the renderer traces and reports them. */
+size_t crt_shard_pixels(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, uint32_t *out);
+
 typedef struct CrtRenderer CrtRenderer; /* Renderer{camera, world, lights, settings} (tracer.rs:137-148) */
 
 /* Renderer::new: binds the committed scene (retained), one material per geom_id (rt_world.rs:111-122),

@@ -1,0 +1,56 @@
+"""The C-ABI library loads and exports every symbol include/crt.h declares (no compute calls: runs without a GPU)."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "crt.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(crt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(crt):
+    names = _declared()
+    assert len(names) >= 40
+    missing = [n for n in names if not hasattr(crt.lib(), n)]
+    assert not missing, missing
+    assert sorted(crt.ABI_SYMBOLS) == names, set(names) ^ set(crt.ABI_SYMBOLS)
+
+
+def test_struct_layouts_match_the_header(crt, tmp_path):
+    """sizeof of every struct, as gcc lays out include/crt.h, equals the ctypes mirror's."""
+    import ctypes as C
+    import subprocess
+    names = ["CrtRay", "CrtRayHit", "CrtMaterial", "CrtLight", "CrtCamera", "CrtRenderSettings", "CrtTravStats", "CrtRayStats"]
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "crt.h"\nint main(void){' +
+                   "".join('printf("%s %%zu\\n", sizeof(%s));' % (n, n) for n in names) + "return 0;}\n")
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for n in names:
+        assert int(out[n]) == C.sizeof(getattr(crt, n)), n
+    assert C.sizeof(crt.CrtRay) == 48 and C.sizeof(crt.CrtRayHit) == 40  # ray.rs:18-23, scene.rs:134-142
+
+
+def test_host_only_entry_points_work_without_a_device(crt):
+    b = crt.SceneBuilder()
+    b.attach_sphere((0, 0, 0), 1.0)
+    s = b.commit()  # host-side build: no HIP call
+    assert s.primitive_count() == 1 and s.geometry_count() == 1
+    assert crt.lib().crt_version().startswith(b"crt_amd")
+    m = crt.default_material()
+    assert abs(m.specular_ior - 1.5) < 1e-7 and m.kind == crt.MAT_OPENPBR
+
+
+def test_no_product_module_touches_the_oracle():
+    """The product path must never import, link or execute anything under oracle/."""
+    pkg = os.path.join(ROOT, "crust-render_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                for needle in ("liboracle", "import ora", '#include "ora', "oracle/_build", "-loracle"):
+                    assert needle not in text, (os.path.join(dirpath, f), needle)
