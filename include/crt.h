@@ -202,8 +202,8 @@ size_t crt_shard_pixels(uint32_t width, uint32_t height, uint32_t rank, uint32_t
 typedef struct CrtRenderer CrtRenderer; /* Renderer{camera, world, lights, settings} (tracer.rs:137-148) */
 
 /* Renderer::new: binds the committed scene (retained), one material per geom_id (rt_world.rs:111-122),
- * the light list (light.rs:392-395) and the camera. Pixel rows [row_begin, row_end) of the frame are this
- * renderer's shard (pixel-tile sharding across ranks; pass 0, height for the whole frame). */
+ * the light list (light.rs:392-395) and the camera. The renderer owns the pixels crt_shard_pixels(width,
+ * height, tile_rank, tile_world) lists (pass 0, 1 for the whole frame). */
 CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, size_t n_materials,
                               const CrtLight *lights, size_t n_lights, const CrtCamera *camera,
                               const CrtRenderSettings *settings, uint32_t tile_rank, uint32_t tile_world);

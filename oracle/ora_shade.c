@@ -724,3 +724,42 @@ void ora_filter_sample(int kind, float r, float u, float *offset, float *weight)
   float x = u < 0.5f ? r * (sqrtf(2.0f * u) - 1.0f) : r * (1.0f - sqrtf(2.0f * (1.0f - u)));
   *offset = 0.5f + x;
 }
+
+/* ------------------------------------------------------------------ */
+/* Exported views of the file-local functions, for the known-answer    */
+/* tests ported from openpbr.rs:1259-2240 (tests/test_oracle_shade.py) */
+/* ------------------------------------------------------------------ */
+float ora_t_sheen_charlie(float nv, float nl, float nh, float roughness) { /* brdf.rs:279-281 */
+  return sheen_charlie_d(nh, roughness) * sheen_charlie_v(nv, nl);
+}
+v3 ora_t_coat_darkening_factor(v3 base_color, float coat_ior, float darkening) {
+  return coat_darkening_factor(base_color, coat_ior, darkening);
+}
+v3 ora_t_coat_attenuation(const OraMaterial *m, float cos_v, float cos_l) { return coat_attenuation(m, cos_v, cos_l); }
+v3 ora_t_eval_coat(const OraMaterial *m, v3 v, v3 l, v3 h, float ax, float ay) { return eval_coat(m, v, l, h, ax, ay); }
+v3 ora_t_thin_film_fresnel_metal(float cos1, float eta1, float eta_film, v3 f0, float thickness_nm) {
+  return thin_film_fresnel_metal(cos1, eta1, eta_film, f0, thickness_nm);
+}
+v3 ora_t_transmission_iors(const OraMaterial *m) { return transmission_iors(m); }
+v3 ora_t_sample_transmission_thin(const OraMaterial *m, v3 ray_dir, const OraHitRecord *rec) {
+  v3 d, thr;
+  sample_transmission_thin(m, ray_dir, rec, &d, &thr);
+  return thr;
+}
+v3 ora_t_light_sample_point(const OraLight *l, float u, float v) { return light_sample_point(l, u, v); }
+v3 ora_t_light_normal_at(const OraLight *l, v3 p) { return light_normal_at(l, p); }
+float ora_t_light_area(const OraLight *l) { return light_area(l); }
+/* sampler (ora_qmc.h is header-only) */
+uint32_t ora_t_sampler_new(int x, int y, int frame, int index) { return ora_sampler_new(x, y, frame, index).pattern; }
+uint32_t ora_t_new_domain(uint32_t pattern, int key) {
+  OraSampler s = {pattern, 0};
+  return ora_new_domain(s, key).pattern;
+}
+void ora_t_draw4(uint32_t pattern, uint32_t index, float out[4]) {
+  OraSampler s = {pattern, index};
+  ora_draw_sample4(s, out);
+}
+float ora_t_rnd1(uint32_t pattern, uint32_t index) {
+  OraSampler s = {pattern, index};
+  return ora_draw_rnd1(s);
+}

@@ -249,6 +249,24 @@ def lib():
     L.ora_cosine_hemisphere.argtypes = [C.c_float, C.c_float]
     L.ora_concentric_disk.restype = V3
     L.ora_concentric_disk.argtypes = [C.c_float, C.c_float]
+    for n, res, args in [
+        ("ora_t_sheen_charlie", C.c_float, [C.c_float] * 4),
+        ("ora_t_coat_darkening_factor", V3, [V3, C.c_float, C.c_float]),
+        ("ora_t_coat_attenuation", V3, [MP, C.c_float, C.c_float]),
+        ("ora_t_eval_coat", V3, [MP, V3, V3, V3, C.c_float, C.c_float]),
+        ("ora_t_thin_film_fresnel_metal", V3, [C.c_float, C.c_float, C.c_float, V3, C.c_float]),
+        ("ora_t_transmission_iors", V3, [MP]),
+        ("ora_t_sample_transmission_thin", V3, [MP, V3, C.POINTER(HitRecord)]),
+        ("ora_t_light_sample_point", V3, [C.POINTER(Light), C.c_float, C.c_float]),
+        ("ora_t_light_normal_at", V3, [C.POINTER(Light), V3]),
+        ("ora_t_light_area", C.c_float, [C.POINTER(Light)]),
+        ("ora_t_sampler_new", C.c_uint32, [C.c_int] * 4),
+        ("ora_t_new_domain", C.c_uint32, [C.c_uint32, C.c_int]),
+        ("ora_t_draw4", None, [C.c_uint32, C.c_uint32, fp]),
+        ("ora_t_rnd1", C.c_float, [C.c_uint32, C.c_uint32]),
+    ]:
+        getattr(L, n).restype = res
+        getattr(L, n).argtypes = args
     L.ora_light_sample_li.argtypes = [C.POINTER(Light), V3, C.c_float, C.c_float, C.POINTER(LightSample)]
     L.ora_light_pdf_at_point.restype = C.c_float
     L.ora_light_pdf_at_point.argtypes = [C.POINTER(Light), V3, V3]
