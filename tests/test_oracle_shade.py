@@ -488,7 +488,7 @@ def test_sampler_is_stratified_and_domains_decorrelate():
     assert ((pts >= 0) & (pts < 1)).all()
     for d in range(4):  # Owen-scrambled Sobol: each 1-D projection of 256 points hits every 1/256 stratum once
         assert len(set((pts[:, d] * 256).astype(int))) == 256
-    for a, b in ((0, 1), (2, 3)):  # (0,2)-sequence pairs: 16x16 strata hold exactly one point each
+    for a, b in ((0, 1), (0, 2), (0, 3), (1, 2)):  # (0,2)-net pairs of Joe-Kuo dims 0-3: one point per 16x16 stratum
         cells = set(zip((pts[:, a] * 16).astype(int), (pts[:, b] * 16).astype(int)))
         assert len(cells) == 256
     other = L.ora_t_new_domain(pat, 7)
