@@ -65,7 +65,15 @@ class CrtRayHit(C.Structure):
 class CrtTravStats(C.Structure):
     _fields_ = [("queries", C.c_uint64 * 2), ("nodes", C.c_uint64 * 2), ("leaves", C.c_uint64 * 2),
                 ("packets", C.c_uint64 * 2), ("prims", C.c_uint64 * 2), ("accepted_hits", C.c_uint64),
-                ("instance_descents", C.c_uint64), ("rays", C.c_uint64)]
+                ("instance_descents", C.c_uint64), ("rays", C.c_uint64),
+                ("phase_waves", C.c_uint64 * 8), ("phase_lanes", C.c_uint64 * 8)]
+
+    PHASES = ("loop", "fetch+setup", "node", "packet", "scalar prim", "instance exit", "emit", "f64 fallback")
+
+    def utilisation(self):
+        """Lane utilisation per traversal phase: {phase: (wave executions, live lanes / 64 per execution)}."""
+        return {n: (int(self.phase_waves[k]), (self.phase_lanes[k] / (64.0 * self.phase_waves[k])) if self.phase_waves[k] else 0.0)
+                for k, n in enumerate(self.PHASES)}
 
     def as_dict(self):
         d = {k: [int(getattr(self, k)[0]), int(getattr(self, k)[1])] for k in ("queries", "nodes", "leaves", "packets",

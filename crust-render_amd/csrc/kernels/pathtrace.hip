@@ -20,6 +20,7 @@
 //   shadow   : any-hit traversal of the shadow queue; unoccluded requests add their contribution
 //   resolve  : staging planes are folded into the film in sample order (sum += color, tracer.rs:599)
 // Path state is struct-of-arrays so every stage's loads and stores are unit-stride across a wave.
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -71,13 +72,48 @@ struct ShadowSoA { float4 *a, *b, *c; };       // origin + tmax; dir + time; con
 // workgroup compacts its own survivors with a wave ballot + popcount prefix and an LDS counter, so the
 // wavefront has NO global atomics on its data path (a single returning atomic per wave on one queue head
 // saturates near 88 M/s on this chip — more than the whole shade stage costs).
+//
+// Direction bins: a workgroup's segment of a PATH buffer is split into kBins sub-segments, one per octant of the
+// ray direction, and shade appends every continuing path to the sub-segment of its new direction. The next
+// extend then walks the sub-segments in turn, so the 64 rays of a wave share their direction signs (same
+// near-to-far child order, similar subtrees) and come from neighbouring pixels: secondary rays regain most of
+// the coherence of camera rays without a sort pass. Price: kBins x the slot index space of the path and hit
+// planes (address space only — untouched slots cost neither bandwidth nor cache; HBM has 288 GB).
+// Measured on cornellbox 1080p (profiles/README.md, r01c): 8 octant bins cut extend by only 3 % and cost shade
+// 15 % — the divergence is between traversal PHASES, not between child orders — so the default is 1 bin.
+#ifndef CRT_BINS
+#define CRT_BINS 1
+#endif
+constexpr int kBins = CRT_BINS;
 constexpr int kMaxGrid = 16384;
 struct Counters {
   uint32_t err;
   uint32_t pad;
-  unsigned long long stats[8];  // RayStats (stats.rs:128-147) in declaration order
-  uint32_t seg[3][kMaxGrid];    // [0], [1]: live paths of state buffer 0 / 1; [2]: shadow requests
+  unsigned long long stats[8];      // RayStats (stats.rs:128-147) in declaration order
+  uint32_t seg[2][kMaxGrid * kBins];  // live paths of state buffer 0 / 1, per (workgroup, bin)
+  uint32_t shadow[kMaxGrid];          // shadow requests per workgroup
 };
+
+__device__ __forceinline__ uint32_t dir_bin(float dx, float dy, float dz) {
+  if (kBins == 1) return 0;
+  return (dx < 0.0f ? 1u : 0u) | (dy < 0.0f ? 2u : 0u) | (dz < 0.0f ? 4u : 0u);
+}
+// Prefix sums of a workgroup's kBins sub-segment counts (pre[kBins] = total); ends with a barrier.
+__device__ __forceinline__ void bins_prefix(const uint32_t *counts, uint32_t *pre /* LDS, kBins + 1 */) {
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (int b = 0; b < kBins; b++) { pre[b] = acc; acc += counts[b]; }
+    pre[kBins] = acc;
+  }
+  __syncthreads();
+}
+// Slot of the k-th live path of this workgroup (sub-segments concatenated in bin order).
+__device__ __forceinline__ uint32_t bin_slot(uint32_t k, const uint32_t *pre, uint32_t seg_cap) {
+  uint32_t b = 0;
+#pragma unroll
+  for (int t = 1; t < kBins; t++) b += k >= pre[t] ? 1u : 0u;
+  return (blockIdx.x * kBins + b) * seg_cap + (k - pre[b]);
+}
 
 struct Params {
   DevScene scene;
@@ -153,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(Params P, PathSoA S, Counte
   // sample of the frame (sky and geometry alike), so the per-segment work stays balanced at every bounce, while
   // a wave still holds 64 consecutive pixels of one 16x16 tile (coherent primary rays).
   const size_t total = (size_t)P.n_pix * n_samples;
-  const size_t seg0 = (size_t)blockIdx.x * P.seg_cap;
+  const size_t seg0 = (size_t)blockIdx.x * kBins * P.seg_cap;  // camera rays are coherent as dealt: all in bin 0
   const size_t G = gridDim.x;
   uint32_t seg_n = 0;
   for (size_t k = threadIdx.x; k < P.seg_cap; k += kBlock) {
@@ -193,9 +229,11 @@ __global__ __launch_bounds__(kBlock) void k_generate(Params P, PathSoA S, Counte
   if (seg_n) atomicMax(&seg_max, seg_n);
   __syncthreads();
   if (threadIdx.x == 0) {
-    C->seg[0][blockIdx.x] = seg_max;
-    C->seg[1][blockIdx.x] = 0;
-    C->seg[2][blockIdx.x] = 0;
+    for (int b = 0; b < kBins; b++) {
+      C->seg[0][blockIdx.x * kBins + b] = b == 0 ? seg_max : 0;
+      C->seg[1][blockIdx.x * kBins + b] = 0;
+    }
+    C->shadow[blockIdx.x] = 0;
     if (blockIdx.x == 0) atomicAdd(&C->stats[0], (unsigned long long)total);  // camera_rays (tracer.rs:585)
   }
 }
@@ -206,12 +244,13 @@ __global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_extend(Params P, P
                                                    CrtTravStats *tstats) {
   __shared__ uint32_t stack[kStackLds * kBlock];
   __shared__ __attribute__((aligned(16))) uint32_t lds_nodes[kLdsNodes * kLdsNodeStride];
-  const uint32_t n = C->seg[cur][blockIdx.x];
+  __shared__ uint32_t pre[kBins + 1];
+  bins_prefix(&C->seg[cur][blockIdx.x * kBins], pre);
+  const uint32_t n = pre[kBins];
   if (n == 0) return;  // uniform per workgroup
   __shared__ uint32_t next;
   if (threadIdx.x == 0) next = 0;
   const uint32_t n_lds = stage_nodes(P.scene, lds_nodes);  // ends with a barrier
-  const uint32_t seg0 = blockIdx.x * P.seg_cap;
   LaneStats st = {};
   uint32_t err = 0, done = 0;
   // every path of the first round is a camera ray, every later one an indirect ray (camera.rs:83, tracer.rs:1516-1519)
@@ -219,7 +258,7 @@ __global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_extend(Params P, P
   auto fetch = [&](bool want, RayIn &in) -> bool {
     uint32_t k;
     if (!lds_take(want, &next, n, k)) return false;
-    const uint32_t i = seg0 + k;
+    const uint32_t i = bin_slot(k, pre, P.seg_cap);
     const float4 A = S.a[i], B = S.b[i];
     in.ox = A.x; in.oy = A.y; in.oz = A.z; in.dx = A.w; in.dy = B.x; in.dz = B.y;
     in.time = P.has_motion ? S.time[i] : 0.0f;
@@ -239,48 +278,33 @@ __global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_extend(Params P, P
   };
   traverse_stream<false, STATS>(P.scene, &stack[threadIdx.x], lds_nodes, n_lds, err, st, fetch, emit);
   if (err) atomicOr(&C->err, err);
-  if (STATS) {
-    auto wave_sum = [](uint32_t v) { for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64); return v; };
-    const bool lead = (threadIdx.x & 63) == 0;
-    for (int k = 0; k < 2; k++) {
-      const uint32_t a = wave_sum(st.queries[k]), b = wave_sum(st.nodes[k]), c = wave_sum(st.leaves[k]);
-      const uint32_t d = wave_sum(st.packets[k]), e = wave_sum(st.prims[k]);
-      if (lead) {
-        atomicAdd((unsigned long long *)&tstats->queries[k], (unsigned long long)a);
-        atomicAdd((unsigned long long *)&tstats->nodes[k], (unsigned long long)b);
-        atomicAdd((unsigned long long *)&tstats->leaves[k], (unsigned long long)c);
-        atomicAdd((unsigned long long *)&tstats->packets[k], (unsigned long long)d);
-        atomicAdd((unsigned long long *)&tstats->prims[k], (unsigned long long)e);
-      }
-    }
-    const uint32_t a = wave_sum(st.accepted), b = wave_sum(st.descents), c = wave_sum(done);
-    if (lead) {
-      atomicAdd((unsigned long long *)&tstats->accepted_hits, (unsigned long long)a);
-      atomicAdd((unsigned long long *)&tstats->instance_descents, (unsigned long long)b);
-      atomicAdd((unsigned long long *)&tstats->rays, (unsigned long long)c);
-    }
-  }
+  if (STATS) flush_stats(st, tstats, done);
 }
 
 // ---- shade: one iteration of trace_path's loop body for every live path (tracer.rs:1118-1530) ----
 __global__ __launch_bounds__(kBlock, CRT_SHADE_WAVES) void k_shade(Params P, PathSoA S, PathSoA N, HitSoA H, ShadowSoA Q, Counters *C,
                                                   int cur, float4 *staging) {
   __shared__ uint32_t sobol_tab[kSobolLdsWords];
-  __shared__ uint32_t lds_ctr[10];  // [0] survivors, [1] shadow requests, [2..8] statistics
-  const uint32_t n = C->seg[cur][blockIdx.x];
+  __shared__ uint32_t lds_ctr[10];  // [1] shadow requests, [2..8] statistics
+  __shared__ uint32_t out_n[kBins];  // survivors per direction bin
+  __shared__ uint32_t pre[kBins + 1];
+  bins_prefix(&C->seg[cur][blockIdx.x * kBins], pre);
+  const uint32_t n = pre[kBins];
   if (n == 0) {  // nothing lives in this segment (uniform per workgroup): publish empty outputs and leave
-    if (threadIdx.x == 0) { C->seg[1 - cur][blockIdx.x] = 0; C->seg[2][blockIdx.x] = 0; }
+    if (threadIdx.x < kBins) C->seg[1 - cur][blockIdx.x * kBins + threadIdx.x] = 0;
+    if (threadIdx.x == 0) C->shadow[blockIdx.x] = 0;
     return;
   }
   if (threadIdx.x < 10) lds_ctr[threadIdx.x] = 0;
+  if (threadIdx.x < kBins) out_n[threadIdx.x] = 0;
   sobol_tables_init(sobol_tab);  // ends with a workgroup barrier
-  const uint32_t seg0 = blockIdx.x * P.seg_cap;
+  const uint32_t seg0 = blockIdx.x * P.seg_cap;  // shadow queue: one unbinned segment per workgroup
   uint32_t s_closest = 0, s_shadow = 0, s_vertices = 0, s_rr_t = 0, s_rr_k = 0, s_esc = 0, s_depth = 0;
   const uint32_t rounds = (n + kBlock - 1) / kBlock;
   for (uint32_t round = 0; round < rounds; round++) {
     const uint32_t k_in = round * kBlock + threadIdx.x;
-    const uint32_t i = seg0 + k_in;
     const bool active = k_in < n;
+    const uint32_t i = active ? bin_slot(k_in, pre, P.seg_cap) : 0;
     bool alive = false, want_shadow = false;
     V3 L = splat(0.0f), beta = splat(1.0f);
     V3 n_o = splat(0.0f), n_d = splat(0.0f), sh_d = splat(0.0f), sh_c = splat(0.0f), hit_p = splat(0.0f);
@@ -418,7 +442,16 @@ __global__ __launch_bounds__(kBlock, CRT_SHADE_WAVES) void k_shade(Params P, Pat
     }
 
     // ---- wave-level compaction: survivors go to the other state buffer, finished paths to the film ----
-    const uint32_t j = seg0 + seg_append(alive, &lds_ctr[0]);
+    uint32_t j = 0;
+    {
+      const uint32_t my_bin = dir_bin(n_d.x, n_d.y, n_d.z);
+#pragma unroll
+      for (int b = 0; b < kBins; b++) {
+        const bool mine = alive && my_bin == (uint32_t)b;
+        const uint32_t pos = seg_append(mine, &out_n[b]);
+        if (mine) j = (blockIdx.x * kBins + b) * P.seg_cap + pos;
+      }
+    }
     const uint32_t sl = aux & 0xffffu;
     const uint32_t film_idx = sl * P.n_pix + pix;
     if (alive) {
@@ -444,9 +477,11 @@ __global__ __launch_bounds__(kBlock, CRT_SHADE_WAVES) void k_shade(Params P, Pat
   add_stat(&lds_ctr[8], s_depth);
   __syncthreads();
   if (threadIdx.x == 0) {  // publish this segment's queues for the next stages (same workgroup index there)
-    C->seg[1 - cur][blockIdx.x] = lds_ctr[0];
-    C->seg[2][blockIdx.x] = lds_ctr[1];
-    C->seg[cur][blockIdx.x] = 0;  // consumed: this buffer is the output of the next round
+    C->shadow[blockIdx.x] = lds_ctr[1];
+  }
+  if (threadIdx.x < kBins) {
+    C->seg[1 - cur][blockIdx.x * kBins + threadIdx.x] = out_n[threadIdx.x];
+    C->seg[cur][blockIdx.x * kBins + threadIdx.x] = 0;  // consumed: this buffer is the output of the next round
   }
   if (threadIdx.x >= 1 && threadIdx.x <= 7 && lds_ctr[threadIdx.x + 1])
     atomicAdd(&C->stats[threadIdx.x], (unsigned long long)lds_ctr[threadIdx.x + 1]);
@@ -458,7 +493,7 @@ __global__ __launch_bounds__(kBlock, CRT_SHADOW_WAVES) void k_shadow(Params P, P
                                                    CrtTravStats *tstats) {
   __shared__ uint32_t stack[kStackLds * kBlock];
   __shared__ __attribute__((aligned(16))) uint32_t lds_nodes[kLdsNodes * kLdsNodeStride];
-  const uint32_t n = C->seg[2][blockIdx.x];
+  const uint32_t n = C->shadow[blockIdx.x];
   if (n == 0) return;  // uniform per workgroup
   __shared__ uint32_t next;
   if (threadIdx.x == 0) next = 0;
@@ -493,27 +528,7 @@ __global__ __launch_bounds__(kBlock, CRT_SHADOW_WAVES) void k_shadow(Params P, P
   };
   traverse_stream<true, STATS>(P.scene, &stack[threadIdx.x], lds_nodes, n_lds, err, st, fetch, emit);
   if (err) atomicOr(&C->err, err);
-  if (STATS) {
-    auto wave_sum = [](uint32_t v) { for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64); return v; };
-    const bool lead = (threadIdx.x & 63) == 0;
-    for (int k = 0; k < 2; k++) {
-      const uint32_t a = wave_sum(st.queries[k]), b = wave_sum(st.nodes[k]), c = wave_sum(st.leaves[k]);
-      const uint32_t d = wave_sum(st.packets[k]), e = wave_sum(st.prims[k]);
-      if (lead) {
-        atomicAdd((unsigned long long *)&tstats->queries[k], (unsigned long long)a);
-        atomicAdd((unsigned long long *)&tstats->nodes[k], (unsigned long long)b);
-        atomicAdd((unsigned long long *)&tstats->leaves[k], (unsigned long long)c);
-        atomicAdd((unsigned long long *)&tstats->packets[k], (unsigned long long)d);
-        atomicAdd((unsigned long long *)&tstats->prims[k], (unsigned long long)e);
-      }
-    }
-    const uint32_t a = wave_sum(st.accepted), b = wave_sum(st.descents), c = wave_sum(done);
-    if (lead) {
-      atomicAdd((unsigned long long *)&tstats->accepted_hits, (unsigned long long)a);
-      atomicAdd((unsigned long long *)&tstats->instance_descents, (unsigned long long)b);
-      atomicAdd((unsigned long long *)&tstats->rays, (unsigned long long)c);
-    }
-  }
+  if (STATS) flush_stats(st, tstats, done);
 }
 
 // ---- resolve: sum += color, in sample order; weight_sum += wx*wy = 1 (tracer.rs:599-600) ----
@@ -596,21 +611,26 @@ struct Renderer {
     if (blob) { (void)hipFree(blob); blob = nullptr; }
     const size_t total = (size_t)P.n_pix * n_samples;
     const size_t seg = ((total + (size_t)grid * kBlock - 1) / ((size_t)grid * kBlock)) * kBlock;  // slots per segment: whole chunks
-    const size_t cap = seg * grid;
-    if (total == 0 || cap >= (size_t)0x7fffffff) return CRT_ERR_BAD_ARG;
+    const size_t cap = seg * grid;        // shadow queue and staging film: one slot per path
+    const size_t bcap = cap * kBins;      // path and hit planes: one sub-segment per (workgroup, direction bin)
+    if (total == 0 || bcap >= (size_t)0x7fffffff) return CRT_ERR_BAD_ARG;
     P.seg_cap = (uint32_t)seg;
-    const size_t p16 = (cap * 16 + 255) & ~size_t(255), p4 = (cap * 4 + 255) & ~size_t(255);
-    // 2 x (a b c d e [16 B] + time [4 B]) + hit (16 + 4) + shadow 3 x 16 + staging 16
-    blob_bytes = 2 * (5 * p16 + p4) + (p16 + p4) + 3 * p16 + p16;
+    const size_t p16 = (cap * 16 + 255) & ~size_t(255);
+    const size_t b16 = (bcap * 16 + 255) & ~size_t(255), b4 = (bcap * 4 + 255) & ~size_t(255);
+    const bool lit = P.n_lights > 0, motion = P.has_motion != 0;
+    // 2 x (a b c d [e] [16 B] + [time 4 B]) + hit (16 + 4) + shadow 3 x 16 + staging 16
+    blob_bytes = 2 * ((lit ? 5 : 4) * b16 + (motion ? b4 : 0)) + (b16 + b4) + (lit ? 3 * p16 : 0) + p16;
     if (!CRT_HIP_OK(hipMalloc(&blob, blob_bytes))) return CRT_ERR_NO_DEVICE;
     char *cur_p = blob;
     auto take = [&](size_t bytes) { char *r = cur_p; cur_p += bytes; return r; };
     for (int b = 0; b < 2; b++) {
-      S[b].a = (float4 *)take(p16); S[b].b = (float4 *)take(p16); S[b].c = (float4 *)take(p16);
-      S[b].d = (uint4 *)take(p16); S[b].e = (float4 *)take(p16); S[b].time = (float *)take(p4);
+      S[b].a = (float4 *)take(b16); S[b].b = (float4 *)take(b16); S[b].c = (float4 *)take(b16);
+      S[b].d = (uint4 *)take(b16);
+      S[b].e = lit ? (float4 *)take(b16) : nullptr;
+      S[b].time = motion ? (float *)take(b4) : nullptr;
     }
-    H.h = (float4 *)take(p16); H.geom = (uint32_t *)take(p4);
-    Q.a = (float4 *)take(p16); Q.b = (float4 *)take(p16); Q.c = (float4 *)take(p16);
+    H.h = (float4 *)take(b16); H.geom = (uint32_t *)take(b4);
+    if (lit) { Q.a = (float4 *)take(p16); Q.b = (float4 *)take(p16); Q.c = (float4 *)take(p16); }
     staging = (float4 *)take(p16);
     cap_samples = n_samples;
     return CRT_OK;
@@ -774,6 +794,7 @@ int crt_render_samples_stats(CrtRenderer *r, uint32_t sample_begin, uint32_t sam
       }
       host_stats[w].accepted_hits += h[w].accepted_hits; host_stats[w].instance_descents += h[w].instance_descents;
       host_stats[w].rays += h[w].rays;
+      for (int k = 0; k < 8; k++) { host_stats[w].phase_waves[k] += h[w].phase_waves[k]; host_stats[w].phase_lanes[k] += h[w].phase_lanes[k]; }
     }
   }
   return rc;
@@ -802,7 +823,8 @@ int crt_film_clear(CrtRenderer *r, void *stream) {
 }
 int crt_render_stats(CrtRenderer *r, CrtRayStats *out) {
   if (!r || !out) return CRT_ERR_BAD_ARG;
-  Counters h;
+  struct { uint32_t err, pad; unsigned long long stats[8]; } h;  // the head of Counters
+  static_assert(offsetof(Counters, seg) == sizeof h, "Counters head layout");
   if (!CRT_HIP_OK(hipStreamSynchronize(r->r.last_stream))) return CRT_ERR_NO_DEVICE;
   if (!CRT_HIP_OK(hipMemcpy(&h, r->r.C, sizeof h, hipMemcpyDeviceToHost))) return CRT_ERR_NO_DEVICE;
   out->camera_rays = h.stats[0]; out->closest_hit = h.stats[1]; out->shadow_rays = h.stats[2];

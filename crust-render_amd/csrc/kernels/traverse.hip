@@ -8,32 +8,6 @@ using namespace dev;
 
 namespace {
 
-__device__ __forceinline__ void flush_stats(const LaneStats &st, CrtTravStats *out, uint32_t rays) {
-  // One atomic per counter per wave: sum across the 64 lanes first.
-  auto wave_sum = [](uint32_t v) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-  };
-  const bool lead = (threadIdx.x & 63) == 0;
-  for (int k = 0; k < 2; k++) {
-    uint32_t a = wave_sum(st.queries[k]), b = wave_sum(st.nodes[k]), c = wave_sum(st.leaves[k]);
-    uint32_t d = wave_sum(st.packets[k]), e = wave_sum(st.prims[k]);
-    if (lead) {
-      atomicAdd((unsigned long long *)&out->queries[k], (unsigned long long)a);
-      atomicAdd((unsigned long long *)&out->nodes[k], (unsigned long long)b);
-      atomicAdd((unsigned long long *)&out->leaves[k], (unsigned long long)c);
-      atomicAdd((unsigned long long *)&out->packets[k], (unsigned long long)d);
-      atomicAdd((unsigned long long *)&out->prims[k], (unsigned long long)e);
-    }
-  }
-  uint32_t a = wave_sum(st.accepted), b = wave_sum(st.descents), c = wave_sum(rays);
-  if (lead) {
-    atomicAdd((unsigned long long *)&out->accepted_hits, (unsigned long long)a);
-    atomicAdd((unsigned long long *)&out->instance_descents, (unsigned long long)b);
-    atomicAdd((unsigned long long *)&out->rays, (unsigned long long)c);
-  }
-}
-
 // Rays are dealt to workgroups in contiguous chunks; inside a workgroup the waves pull them from an LDS
 // counter as their lanes fall idle (persistent-wave scheduling, see traverse_stream).
 struct Chunk { size_t first, count; };

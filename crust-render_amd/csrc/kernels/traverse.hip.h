@@ -50,7 +50,34 @@ struct Hit {
 struct LaneStats {
   uint32_t queries[2], nodes[2], leaves[2], packets[2], prims[2];
   uint32_t accepted, descents;
+  uint32_t ph_wave[8], ph_lane[8];  // CrtTravStats::phase_waves / phase_lanes
 };
+// Counts one execution of a phase: every live lane counts itself, the first live lane counts the wave.
+#define CRT_PHASE(k)                                                        \
+  if (STATS) {                                                              \
+    const unsigned long long m_ = __ballot(1);                              \
+    st.ph_lane[k]++;                                                        \
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) st.ph_wave[k]++; \
+  }
+
+// One atomic per counter per wave: sum across the 64 lanes first.
+__device__ __forceinline__ void flush_stats(const LaneStats &st, CrtTravStats *out, uint32_t rays) {
+  auto wave_sum = [](uint32_t v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+  };
+  const bool lead = (threadIdx.x & 63) == 0;
+  auto add = [&](uint64_t *dst, uint32_t v) {
+    v = wave_sum(v);
+    if (lead && v) atomicAdd((unsigned long long *)dst, (unsigned long long)v);
+  };
+  for (int k = 0; k < 2; k++) {
+    add(&out->queries[k], st.queries[k]); add(&out->nodes[k], st.nodes[k]); add(&out->leaves[k], st.leaves[k]);
+    add(&out->packets[k], st.packets[k]); add(&out->prims[k], st.prims[k]);
+  }
+  add(&out->accepted_hits, st.accepted); add(&out->instance_descents, st.descents); add(&out->rays, rays);
+  for (int k = 0; k < 8; k++) { add(&out->phase_waves[k], st.ph_wave[k]); add(&out->phase_lanes[k], st.ph_lane[k]); }
+}
 
 __device__ __forceinline__ float absf(float x) { return __uint_as_float(__float_as_uint(x) & 0x7fffffffu); }
 __device__ __forceinline__ float copysgn(float mag, float sgn) {
@@ -355,6 +382,7 @@ __device__ void traverse_stream(const DevScene &S, uint32_t *lds /* &stack[tid] 
   auto step = [&]() -> int {
     // ---- continue a leaf's one-at-a-time primitives (bvh.rs:564-570 / :646-651) ----
     if (cursor < cend) {
+      CRT_PHASE(4)
       const uint32_t pi = S.indices[cursor++];
       const DevPrim *p = &S.prims[pi];
       const uint4 hd = *reinterpret_cast<const uint4 *>(p);  // kind, geom_id, prim_id, mask
@@ -434,6 +462,7 @@ __device__ void traverse_stream(const DevScene &S, uint32_t *lds /* &stack[tid] 
     // ---- this tree is exhausted ----
     if ((uint32_t)sp == base) {
       if (level == 0) return 1;
+      CRT_PHASE(5)
       const bool inner_found = (found >> level) & 1u;
       level--;
       const Frame &f = frames[level];
@@ -476,6 +505,7 @@ __device__ void traverse_stream(const DevScene &S, uint32_t *lds /* &stack[tid] 
     while ((uint32_t)sp > base) {
       e = pop();
       if (e & kLeafTag) { have_leaf = true; break; }
+      CRT_PHASE(2)
       expand_node(e);
     }
     if (!have_leaf) return 0;  // exhausted: the check at the top of the loop returns or finishes
@@ -500,6 +530,7 @@ __device__ void traverse_stream(const DevScene &S, uint32_t *lds /* &stack[tid] 
             if ((meta.x & (1u << l)) && (pk->masks[l] & rmask)) m |= 1u << l;
         }
         if (m == 0) continue;
+        CRT_PHASE(3)
         // 9 plane loads, addressed by the permuted axes: v[vertex][axis][0..3]
         const float4 *pl = reinterpret_cast<const float4 *>(&pk->v[0][0][0]);
         const float4 A_x = pl[0 + r.kx], A_y = pl[0 + r.ky], A_z = pl[0 + r.kz];
@@ -560,6 +591,7 @@ __device__ void traverse_stream(const DevScene &S, uint32_t *lds /* &stack[tid] 
             const uint32_t pi = pk->prim[l];
             const DevPrim *p = &S.prims[pi];
             if ((rmask & p->mask) == 0) continue;
+            CRT_PHASE(7)
             float t, u, v;
             if (!tri_scalar(r, p->d, t_min, closest, t, u, v)) continue;
             if (ANY) return 5;  // occluded by an on-edge (f64 fallback) lane
@@ -585,6 +617,7 @@ __device__ void traverse_stream(const DevScene &S, uint32_t *lds /* &stack[tid] 
     if (more && (act == 0 || 64 - __popcll(act) >= kRefillIdle)) {
       RayIn in;
       if (fetch(!active, in)) {
+        CRT_PHASE(1)
         begin(in);
         active = true;
       }
@@ -592,8 +625,10 @@ __device__ void traverse_stream(const DevScene &S, uint32_t *lds /* &stack[tid] 
     }
     if (!__ballot(active)) break;
     if (active) {
+      CRT_PHASE(0)
       const int rc = step();
       if (rc) {
+        CRT_PHASE(6)
         Hit hit;
         bool is_hit;
         if (ANY) {

@@ -67,6 +67,12 @@ typedef struct CrtRayHit {
 typedef struct CrtTravStats {
   uint64_t queries[2], nodes[2], leaves[2], packets[2], prims[2];
   uint64_t accepted_hits, instance_descents, rays;
+  /* SIMD-utilisation counters of the device kernels (no reference counterpart): for each traversal phase,
+   * how many times a wave executed it (phase_waves) and how many of its 64 lanes were live in total
+   * (phase_lanes); lanes/(64*waves) is the phase's lane utilisation. Phases: 0 scheduling loop, 1 ray
+   * fetch + setup, 2 node expansion, 3 packet test, 4 scalar-list primitive, 5 instance exit, 6 emit,
+   * 7 on-edge f64 fallback. */
+  uint64_t phase_waves[8], phase_lanes[8];
 } CrtTravStats;
 
 typedef struct CrtBuilder CrtBuilder; /* crust_rt::SceneBuilder (scene.rs:147-149) */

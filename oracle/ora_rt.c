@@ -383,6 +383,13 @@ static __thread OraTravStats *g_stats = NULL;
 static __thread int g_depth = 0;
 void ora_set_trav_stats(OraTravStats *st) { g_stats = st; }
 #define TSTAT(field, n) do { if (g_stats) g_stats->field[g_depth > 0] += (n); } while (0)
+/* Optional per-ray phase trace for scheduling studies (profiles/simulate_scheduling.py): one char per unit of
+ * traversal work in execution order — N node, P packet, s sphere, I instance entry, X instance exit. */
+static __thread char *g_trace = NULL;
+static __thread size_t g_trace_cap = 0, g_trace_len = 0;
+void ora_set_trace(char *buf, size_t cap) { g_trace = buf; g_trace_cap = cap; g_trace_len = 0; }
+size_t ora_trace_len(void) { return g_trace_len; }
+#define TRACE(c) do { if (g_trace && g_trace_len < g_trace_cap) g_trace[g_trace_len++] = (c); } while (0)
 
 static int bvh_hit(const Bvh *b, const OraRay *ray, float t_min, float t_max, OraPrimHit *out);
 static int bvh_hit_any(const Bvh *b, const OraRay *ray, float t_min, float t_max);
@@ -449,6 +456,7 @@ static int prim_hit(const Prim *p, const OraRay *ray, float t_min, float t_max, 
       return tri_hit_from_bary(p, t, u, v, out);
     }
     case PRIM_SPHERE: { /* prim.rs:133-161 */
+      TRACE('s');
       v3 oc = v3_sub(ray->origin, p->center);
       float a = v3_len2(ray->dir);
       float half_b = v3_dot(oc, ray->dir);
@@ -471,9 +479,11 @@ static int prim_hit(const Prim *p, const OraRay *ray, float t_min, float t_max, 
       inst_transforms_at(p, ray->time, &w2l, &nm);
       OraRay local = {affine_point(&w2l, ray->origin), affine_vector(&w2l, ray->dir), ray->time, ray->mask};
       if (g_stats) g_stats->instance_descents++;
+      TRACE('I');
       g_depth++;
       int hit = bvh_hit(&p->scene->bvh, &local, t_min, t_max, out);
       g_depth--;
+      TRACE('X');
       if (!hit) return 0;
       out->outward = v3_normalize(mat3_mul_v(&nm, out->outward));
       out->geom_id = p->geom_id;
@@ -920,6 +930,7 @@ static int intersect_leaf(const Bvh *b, uint32_t leaf_idx, const OraRay *ray, co
   int found = 0;
   for (uint32_t k = 0; k < leaf->pkt_count; k++) {
     const OraTri4 *pk = &b->packets[leaf->pkt_first + k];
+    TRACE('P');
     Hit4 h = tri4_intersect(pk, sh, ray->origin, ray->mask, t_min, closest);
     for (int lane = 0; lane < 4; lane++) {
       if (!(h.hits & (1u << lane))) continue;
@@ -983,6 +994,7 @@ static int bvh_hit(const Bvh *b, const OraRay *ray, float t_min, float t_max, Or
   while (sp > 0) {
     uint32_t node_idx = stack[--sp];
     TSTAT(nodes, 1);
+    TRACE('N');
     const OraWideNode *nd = &b->wide[node_idx];
     float tn[4]; uint32_t mask = 0;
     for (int l = 0; l < 4; l++) {

@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Offline study of wave scheduling policies for the BVH4 traversal kernel (not part of the product or tests).
+
+Takes real per-ray work sequences from the oracle's phase trace (N node, P packet, s sphere, I instance entry,
+X instance exit) for camera rays and for cosine-distributed bounce rays of the cornellbox scene, in the pixel
+order the renderer uses (16x16 tiles, 64 consecutive pixels per wave), and replays them through models of
+ A  the shipped kernel: while-while step() per lane, refill when >= 32 lanes idle
+ B  majority-vote phase scheduling with register-resident state (one ray per lane)
+ C  a per-wave pool of R rays in LDS, 64 rays of one phase gathered per step
+Cost model: VALU instructions per wave-level execution of a phase (from the gfx950 disassembly, rounded).
+Prints wave-instructions per ray and mean lane utilisation per policy."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+import ora  # noqa: E402
+import ora_world  # noqa: E402
+from __graft_entry__ import load_package  # noqa: E402
+
+COST = dict(F=150, N=140, P=300, s=80, I=250, X=200, E=120, loop=30, queue=50)
+
+
+def traces(scene, rays):
+    L = ora.lib()
+    L.ora_set_trace.argtypes = [C.c_char_p, C.c_size_t]
+    L.ora_trace_len.restype = C.c_size_t
+    buf = C.create_string_buffer(4096)
+    out = []
+    for r in rays:
+        L.ora_set_trace(buf, 4096)
+        scene.intersect(ora.ray(r[0:3], r[3:6], mask=4))
+        out.append(buf.raw[: L.ora_trace_len()].decode())
+    L.ora_set_trace(None, 0)
+    return out
+
+
+def to_steps(tr):
+    """Group a trace into the shipped kernel's step() calls: each call is one scalar prim / one instance exit /
+    a run of N followed by the packets of one leaf."""
+    steps, i = [], 0
+    while i < len(tr):
+        c = tr[i]
+        if c in "sIX":
+            steps.append(c); i += 1
+        else:
+            j = i
+            while j < len(tr) and tr[j] == "N":
+                j += 1
+            k = j
+            while k < len(tr) and tr[k] == "P":
+                k += 1
+            steps.append(tr[i:k]); i = k
+    return steps
+
+
+def sim_A(all_steps, refill=32):
+    """while-while: each iteration every active lane runs one step(); wave cost = sum over the branch kinds
+    present (+ max N run + max P run)."""
+    instr = useful = 0
+    nxt = 0
+    lanes = [None] * 64  # (steps, pos)
+    n = len(all_steps)
+    while True:
+        idle = [k for k in range(64) if lanes[k] is None]
+        if nxt < n and (len(idle) == 64 or len(idle) >= refill):
+            take = idle[: n - nxt]
+            for k in take:
+                lanes[k] = [all_steps[nxt], 0]; nxt += 1
+            instr += COST["F"]; useful += COST["F"] * len(take)
+        act = [k for k in range(64) if lanes[k] is not None]
+        if not act:
+            break
+        instr += COST["loop"]; useful += COST["loop"] * len(act)
+        maxN = maxP = 0
+        kinds = {}
+        emit = 0
+        for k in act:
+            st, pos = lanes[k]
+            if pos >= len(st):
+                emit += 1; lanes[k] = None; continue
+            s = st[pos]; lanes[k][1] += 1
+            if s in ("s", "I", "X"):
+                kinds[s] = kinds.get(s, 0) + 1
+            else:
+                nN, nP = s.count("N"), s.count("P")
+                maxN, maxP = max(maxN, nN), max(maxP, nP)
+                useful += nN * COST["N"] + nP * COST["P"]
+        instr += maxN * COST["N"] + maxP * COST["P"]
+        for s, c in kinds.items():
+            instr += COST[s]; useful += COST[s] * c
+        if emit:
+            instr += COST["E"]; useful += COST["E"] * emit
+    return instr, useful
+
+
+def sim_pool(all_tr, pool=128, lanes=64, rare_min=16, overhead=None):
+    """Pool of `pool` rays per wave; each iteration runs ONE phase for up to 64 rays in that phase. pool == 64
+    with overhead 0 models policy B (register state, majority vote): a ray never changes lane."""
+    overhead = COST["queue"] if overhead is None else overhead
+    instr = useful = 0
+    n = len(all_tr)
+    nxt = 0
+    live = []  # [trace, pos]
+    while True:
+        if nxt < n and pool - len(live) >= min(lanes, n - nxt) and (pool - len(live) >= lanes or not live):
+            take = min(lanes, n - nxt, pool - len(live))
+            for _ in range(take):
+                live.append([all_tr[nxt], 0]); nxt += 1
+            instr += COST["F"] + overhead; useful += COST["F"] * take
+            continue
+        if not live:
+            break
+        by = {}
+        for r in live:
+            ph = r[0][r[1]] if r[1] < len(r[0]) else "E"
+            by.setdefault(ph, []).append(r)
+        # common phases by majority; rare phases wait until rare_min rays queue up or nothing else is runnable
+        common = {p: v for p, v in by.items() if p in "NP"}
+        rare = {p: v for p, v in by.items() if p not in "NP" and len(v) >= rare_min}
+        cand = rare or common or by
+        if common and not rare:
+            cand = common
+        ph, rs = max(cand.items(), key=lambda kv: len(kv[1]))
+        rs = rs[:lanes]
+        instr += COST[ph] + overhead; useful += COST[ph] * len(rs)
+        for r in rs:
+            if ph == "E":
+                live.remove(r)
+            else:
+                r[1] += 1
+    return instr, useful
+
+
+def main():
+    crt = load_package()
+    w, h = 128, 64
+    desc = crt.usda.load(os.path.join(ROOT, "scenes", "cornellbox.usda"), w, h)
+    o = ora_world.OracleRenderer(desc, crt.usda)
+    cam = o.job.camera
+    pix = crt.shard.shard_pixels(w, h, 0, 1)  # tile order, as the renderer traces
+    rng = np.random.default_rng(1)
+    prim = np.zeros((len(pix), 8), dtype=np.float32)
+    L = ora.lib()
+    for k, p in enumerate(pix):
+        i, j = int(p) % w, int(p) // w
+        r = ora.Ray()
+        L.ora_camera_get_ray(C.byref(cam), (i + 0.5) / w, (j + 0.5) / h, 0.5, 0.5, 0.0, C.byref(r))
+        prim[k, 0:3] = r.origin.np(); prim[k, 3:6] = r.dir.np()
+    prim[:, 7] = np.array([1], dtype=np.uint32).view(np.float32)
+    hf, ids, front = o.scene.intersect_n(prim, 0.001, float("inf"))
+    hit = ids[:, 0] != 0xFFFFFFFF
+    sec = []
+    for k in np.nonzero(hit)[0]:
+        nrm = hf[k, 1:4].astype(np.float64)
+        pnt = prim[k, 0:3] + prim[k, 3:6] * hf[k, 0]
+        a = np.array([1.0, 0, 0]) if abs(nrm[0]) < 0.9 else np.array([0, 1.0, 0])
+        t = np.cross(nrm, a); t /= np.linalg.norm(t); b = np.cross(nrm, t)
+        u1, u2 = rng.random(2)
+        rr, ph = np.sqrt(u1), 2 * np.pi * u2
+        d = t * rr * np.cos(ph) + b * rr * np.sin(ph) + nrm * np.sqrt(1 - u1)
+        sec.append(np.concatenate([pnt, d]))
+    sec = np.array(sec, dtype=np.float32)
+    for label, rays in (("camera rays", prim[:, :6]), ("bounce rays (cosine about the hit normal)", sec)):
+        tr = traces(o.scene, rays)
+        steps = [to_steps(t) for t in tr]
+        nN = sum(t.count("N") for t in tr) / len(tr); nP = sum(t.count("P") for t in tr) / len(tr)
+        nI = sum(t.count("I") for t in tr) / len(tr)
+        print(f"== {label}: {len(tr)} rays, {nN:.2f} nodes, {nP:.2f} packets, {nI:.3f} instance entries per ray")
+        for name, (ins, use) in (
+            ("A while-while, refill 32", sim_A(steps)),
+            ("B majority vote, registers", sim_pool(tr, pool=64, overhead=10)),
+            ("C pool 96 in LDS", sim_pool(tr, pool=96)),
+            ("C pool 128 in LDS", sim_pool(tr, pool=128)),
+            ("C pool 192 in LDS", sim_pool(tr, pool=192)),
+        ):
+            print(f"   {name:28s} wave-instr/ray {ins / len(tr):7.2f}   lane utilisation {use / (64.0 * ins):5.3f}")
+
+
+if __name__ == "__main__":
+    main()
