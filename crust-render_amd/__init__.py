@@ -66,7 +66,8 @@ class CrtTravStats(C.Structure):
     _fields_ = [("queries", C.c_uint64 * 2), ("nodes", C.c_uint64 * 2), ("leaves", C.c_uint64 * 2),
                 ("packets", C.c_uint64 * 2), ("prims", C.c_uint64 * 2), ("accepted_hits", C.c_uint64),
                 ("instance_descents", C.c_uint64), ("rays", C.c_uint64),
-                ("phase_waves", C.c_uint64 * 8), ("phase_lanes", C.c_uint64 * 8)]
+                ("phase_waves", C.c_uint64 * 8), ("phase_lanes", C.c_uint64 * 8),
+                ("phase_cycles", C.c_uint64 * 8)]
 
     PHASES = ("loop", "fetch+setup", "node", "packet", "scalar prim", "instance exit", "emit", "f64 fallback")
 

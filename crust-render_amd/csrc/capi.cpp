@@ -224,7 +224,7 @@ static int with_stats(CrtScene *s, void *stream, CrtTravStats *host_stats,
     host_stats->accepted_hits += h.accepted_hits;
     host_stats->instance_descents += h.instance_descents;
     host_stats->rays += h.rays;
-    for (int k = 0; k < 8; k++) { host_stats->phase_waves[k] += h.phase_waves[k]; host_stats->phase_lanes[k] += h.phase_lanes[k]; }
+    for (int k = 0; k < 8; k++) { host_stats->phase_waves[k] += h.phase_waves[k]; host_stats->phase_lanes[k] += h.phase_lanes[k]; host_stats->phase_cycles[k] += h.phase_cycles[k]; }
   }
   return rc;
 }

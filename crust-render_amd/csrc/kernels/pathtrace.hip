@@ -27,7 +27,7 @@
 #include <vector>
 
 #include "shade.hip.h"
-#include "traverse.hip.h"
+#include "traverse_pool.hip.h"
 
 namespace crt {
 
@@ -43,7 +43,7 @@ namespace {
 #define CRT_SHADE_WAVES 3
 #endif
 #ifndef CRT_SHADOW_WAVES
-#define CRT_SHADOW_WAVES 4
+#define CRT_SHADOW_WAVES 3
 #endif
 
 enum { K_CAMERA = 0, K_PATH = 1, K_TIME = 2 };                 // tracer.rs:20-22 (off root)
@@ -242,15 +242,13 @@ __global__ __launch_bounds__(kBlock) void k_generate(Params P, PathSoA S, Counte
 template <bool STATS>
 __global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_extend(Params P, PathSoA S, HitSoA H, Counters *C, int cur, int first,
                                                    CrtTravStats *tstats) {
-  __shared__ uint32_t stack[kStackLds * kBlock];
-  __shared__ __attribute__((aligned(16))) uint32_t lds_nodes[kLdsNodes * kLdsNodeStride];
+  __shared__ __attribute__((aligned(16))) uint32_t engine_lds[kEngineLdsDwords];
   __shared__ uint32_t pre[kBins + 1];
   bins_prefix(&C->seg[cur][blockIdx.x * kBins], pre);
   const uint32_t n = pre[kBins];
   if (n == 0) return;  // uniform per workgroup
   __shared__ uint32_t next;
   if (threadIdx.x == 0) next = 0;
-  const uint32_t n_lds = stage_nodes(P.scene, lds_nodes);  // ends with a barrier
   LaneStats st = {};
   uint32_t err = 0, done = 0;
   // every path of the first round is a camera ray, every later one an indirect ray (camera.rs:83, tracer.rs:1516-1519)
@@ -276,7 +274,7 @@ __global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_extend(Params P, P
     }
     done++;
   };
-  traverse_stream<false, STATS>(P.scene, &stack[threadIdx.x], lds_nodes, n_lds, err, st, fetch, emit);
+  run_traversal<false, STATS>(P.scene, engine_lds, 0.001f, err, st, fetch, emit);
   if (err) atomicOr(&C->err, err);
   if (STATS) flush_stats(st, tstats, done);
 }
@@ -491,13 +489,11 @@ __global__ __launch_bounds__(kBlock, CRT_SHADE_WAVES) void k_shade(Params P, Pat
 template <bool STATS>
 __global__ __launch_bounds__(kBlock, CRT_SHADOW_WAVES) void k_shadow(Params P, PathSoA N, ShadowSoA Q, Counters *C, float4 *staging,
                                                    CrtTravStats *tstats) {
-  __shared__ uint32_t stack[kStackLds * kBlock];
-  __shared__ __attribute__((aligned(16))) uint32_t lds_nodes[kLdsNodes * kLdsNodeStride];
+  __shared__ __attribute__((aligned(16))) uint32_t engine_lds[kEngineLdsDwords];
   const uint32_t n = C->shadow[blockIdx.x];
   if (n == 0) return;  // uniform per workgroup
   __shared__ uint32_t next;
   if (threadIdx.x == 0) next = 0;
-  const uint32_t n_lds = stage_nodes(P.scene, lds_nodes);  // ends with a barrier
   const uint32_t seg0 = blockIdx.x * P.seg_cap;
   LaneStats st = {};
   uint32_t err = 0, done = 0;
@@ -526,7 +522,7 @@ __global__ __launch_bounds__(kBlock, CRT_SHADOW_WAVES) void k_shadow(Params P, P
       N.c[tg] = v;
     }
   };
-  traverse_stream<true, STATS>(P.scene, &stack[threadIdx.x], lds_nodes, n_lds, err, st, fetch, emit);
+  run_traversal<true, STATS>(P.scene, engine_lds, 0.001f, err, st, fetch, emit);
   if (err) atomicOr(&C->err, err);
   if (STATS) flush_stats(st, tstats, done);
 }
@@ -757,8 +753,10 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
   hipDeviceProp_t prop;
   int dev = 0;
   (void)hipGetDevice(&dev);
-  int mult = 16;
-  if (const char *e = getenv("CRT_GRID_MULT")) mult = atoi(e) > 0 ? atoi(e) : 16;  // tuning knob (workgroups per CU)
+  // Workgroups per CU = queue segments per CU. 3 is what stays resident (LDS of the traversal engine), so every
+  // segment is as long as it can be and a wave's ray pool drains only once per launch.
+  int mult = 3;
+  if (const char *e = getenv("CRT_GRID_MULT")) mult = atoi(e) > 0 ? atoi(e) : 3;  // tuning knob
   if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) r.grid = prop.multiProcessorCount * mult;
   if (r.grid > kMaxGrid) r.grid = kMaxGrid;
   return R;
@@ -794,7 +792,7 @@ int crt_render_samples_stats(CrtRenderer *r, uint32_t sample_begin, uint32_t sam
       }
       host_stats[w].accepted_hits += h[w].accepted_hits; host_stats[w].instance_descents += h[w].instance_descents;
       host_stats[w].rays += h[w].rays;
-      for (int k = 0; k < 8; k++) { host_stats[w].phase_waves[k] += h[w].phase_waves[k]; host_stats[w].phase_lanes[k] += h[w].phase_lanes[k]; }
+      for (int k = 0; k < 8; k++) { host_stats[w].phase_waves[k] += h[w].phase_waves[k]; host_stats[w].phase_lanes[k] += h[w].phase_lanes[k]; host_stats[w].phase_cycles[k] += h[w].phase_cycles[k]; }
     }
   }
   return rc;

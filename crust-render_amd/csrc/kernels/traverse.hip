@@ -1,6 +1,6 @@
 // Batched Scene::intersect / Scene::occluded kernels (scene.rs:354-372) over the device image.
 // Compile with -ffp-contract=off (see traverse.hip.h).
-#include "traverse.hip.h"
+#include "traverse_pool.hip.h"
 
 namespace crt {
 
@@ -32,13 +32,11 @@ template <bool STATS>
 __global__ __launch_bounds__(kBlock) void intersect_n_kernel(DevScene S, const CrtRay *__restrict__ rays, size_t n,
                                                             float t_min, float t_max, CrtRayHit *__restrict__ hits,
                                                             uint32_t *__restrict__ err_out, CrtTravStats *stats) {
-  __shared__ uint32_t stack[kStackLds * kBlock];
-  __shared__ __attribute__((aligned(16))) uint32_t lds_nodes[kLdsNodes * kLdsNodeStride];
+  __shared__ __attribute__((aligned(16))) uint32_t engine_lds[kEngineLdsDwords];
   __shared__ uint32_t next;
   const Chunk ck = my_chunk(n);
   if (ck.count == 0) return;
   if (threadIdx.x == 0) next = 0;
-  const uint32_t n_lds = stage_nodes(S, lds_nodes);  // ends with a barrier
   LaneStats st = {};
   uint32_t err = 0, done = 0;
   auto fetch = [&](bool want, RayIn &in) -> bool {
@@ -69,7 +67,7 @@ __global__ __launch_bounds__(kBlock) void intersect_n_kernel(DevScene S, const C
     hits[i] = out;
     done++;
   };
-  traverse_stream<false, STATS>(S, &stack[threadIdx.x], lds_nodes, n_lds, err, st, fetch, emit);
+  run_traversal<false, STATS>(S, engine_lds, t_min, err, st, fetch, emit);
   if (err) atomicOr(err_out, err);
   if (STATS) flush_stats(st, stats, done);
 }
@@ -78,13 +76,11 @@ template <bool STATS>
 __global__ __launch_bounds__(kBlock) void occluded_n_kernel(DevScene S, const CrtRay *__restrict__ rays, size_t n,
                                                            float t_min, float t_max, uint32_t *__restrict__ out,
                                                            uint32_t *__restrict__ err_out, CrtTravStats *stats) {
-  __shared__ uint32_t stack[kStackLds * kBlock];
-  __shared__ __attribute__((aligned(16))) uint32_t lds_nodes[kLdsNodes * kLdsNodeStride];
+  __shared__ __attribute__((aligned(16))) uint32_t engine_lds[kEngineLdsDwords];
   __shared__ uint32_t next;
   const Chunk ck = my_chunk(n);
   if (ck.count == 0) return;
   if (threadIdx.x == 0) next = 0;
-  const uint32_t n_lds = stage_nodes(S, lds_nodes);
   LaneStats st = {};
   uint32_t err = 0, done = 0;
   auto fetch = [&](bool want, RayIn &in) -> bool {
@@ -100,7 +96,7 @@ __global__ __launch_bounds__(kBlock) void occluded_n_kernel(DevScene S, const Cr
     out[ck.first + k] = occ ? 1u : 0u;
     done++;
   };
-  traverse_stream<true, STATS>(S, &stack[threadIdx.x], lds_nodes, n_lds, err, st, fetch, emit);
+  run_traversal<true, STATS>(S, engine_lds, t_min, err, st, fetch, emit);
   if (err) atomicOr(err_out, err);
   if (STATS) flush_stats(st, stats, done);
 }
@@ -124,7 +120,7 @@ int grid_for(size_t n) {
     return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }();
   size_t need = (n + kBlock - 1) / kBlock;
-  size_t cap = (size_t)cus * 8;  // persistent grid: up to 8 workgroups (32 waves) per CU, grid-stride beyond
+  size_t cap = (size_t)cus * 3;  // what stays resident per CU (LDS of the traversal engine): one chunk per workgroup
   return (int)(need < cap ? (need ? need : 1) : cap);
 }
 

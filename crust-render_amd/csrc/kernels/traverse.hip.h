@@ -51,6 +51,7 @@ struct LaneStats {
   uint32_t queries[2], nodes[2], leaves[2], packets[2], prims[2];
   uint32_t accepted, descents;
   uint32_t ph_wave[8], ph_lane[8];  // CrtTravStats::phase_waves / phase_lanes
+  unsigned long long ph_cyc[8];     // CrtTravStats::phase_cycles (lane 0 of each wave counts)
 };
 // Counts one execution of a phase: every live lane counts itself, the first live lane counts the wave.
 #define CRT_PHASE(k)                                                        \
@@ -77,6 +78,9 @@ __device__ __forceinline__ void flush_stats(const LaneStats &st, CrtTravStats *o
   }
   add(&out->accepted_hits, st.accepted); add(&out->instance_descents, st.descents); add(&out->rays, rays);
   for (int k = 0; k < 8; k++) { add(&out->phase_waves[k], st.ph_wave[k]); add(&out->phase_lanes[k], st.ph_lane[k]); }
+  if (lead)
+    for (int k = 0; k < 8; k++)
+      if (st.ph_cyc[k]) atomicAdd((unsigned long long *)&out->phase_cycles[k], st.ph_cyc[k]);
 }
 
 __device__ __forceinline__ float absf(float x) { return __uint_as_float(__float_as_uint(x) & 0x7fffffffu); }
@@ -203,8 +207,8 @@ __device__ __forceinline__ void motion_w2l(const DevInstance &in, float time, fl
 }
 
 // Cooperative copy of the top-of-tree window into LDS; returns the number of nodes staged. Ends with a barrier.
-__device__ __forceinline__ uint32_t stage_nodes(const DevScene &S, uint32_t *lds_nodes) {
-  const uint32_t n = S.n_nodes < (uint32_t)kLdsNodes ? S.n_nodes : (uint32_t)kLdsNodes;
+__device__ __forceinline__ uint32_t stage_nodes(const DevScene &S, uint32_t *lds_nodes, int cap = kLdsNodes) {
+  const uint32_t n = S.n_nodes < (uint32_t)cap ? S.n_nodes : (uint32_t)cap;
   for (uint32_t w = threadIdx.x; w < n * 8u; w += blockDim.x) {  // 8 x 16 bytes per node
     const uint32_t node = w >> 3, part = w & 7u;
     const float4 v = reinterpret_cast<const float4 *>(S.nodes + node)[part];

@@ -1,0 +1,733 @@
+// BVH4 traversal, phase-scheduled: every lane of a wave owns ROWS rays whose state lives in LDS, and in each
+// step the whole wave executes ONE kind of work — node expansion, packet test, scalar primitive, instance exit,
+// emit, or fetch — for the lanes that have a ray waiting for exactly that.
+//
+// Why: with one ray per lane (traverse.hip.h) incoherent rays sit in different phases of their traversal, and the
+// wave pays for every phase with the few lanes that are in it: measured on cornellbox 1080p, 35 % of the lanes are
+// live in a node expansion, 38 % in a packet test, 5 % in an instance entry or exit (CrtTravStats::phase_lanes).
+// Replaying the oracle's per-ray work traces through both schedulers (profiles/simulate_scheduling.py) predicts
+// 2.2x fewer wave instructions per bounce ray for two rays per lane. The per-ray sequence of operations — node
+// order, leaf order, packet order, accept rule — is untouched, so results stay bit-identical to the reference
+// restatement; only WHEN a ray advances changes.
+//
+// Layout: slot (row, lane) is only ever touched by that lane, so every LDS access of a wave is unit-stride
+// (16 bytes per lane for the state groups, 4 for a stack entry) and conflict-free, and no gather list is needed.
+// State per ray in LDS: five 16-byte groups + kPoolStack stack entries. Rarely used state (direction, time,
+// pending normal, instance frames, deep stack) sits in per-lane private memory indexed by row.
+#pragma once
+
+#include "traverse.hip.h"
+
+namespace crt {
+namespace dev {
+
+#ifndef CRT_POOL_STACK
+#define CRT_POOL_STACK 6
+#endif
+#ifndef CRT_FETCH_MIN
+#define CRT_FETCH_MIN 32
+#endif
+#ifndef CRT_RARE_MIN
+#define CRT_RARE_MIN 16
+#endif
+constexpr int kPoolStack = CRT_POOL_STACK;   // stack entries per ray kept in LDS; deeper entries go to private memory
+constexpr int kPoolSpill = 256 - kPoolStack; // same total capacity as the one-ray-per-lane kernel
+constexpr int kFetchMin = CRT_FETCH_MIN;     // fetch new rays once this many lanes have a free slot
+constexpr int kRareMin = CRT_RARE_MIN;       // run a rare phase (scalar prim / instance exit / emit) at this many lanes
+#ifndef CRT_STICKY_MIN
+#define CRT_STICKY_MIN 24
+#endif
+constexpr int kStickyMin = CRT_STICKY_MIN;   // keep repeating node / packet steps while this many lanes stay in the phase
+
+// LDS dwords one wave needs for ROWS rays per lane.
+template <int ROWS>
+constexpr int pool_lds_dwords() { return (4 + 4 + 2 + 5 + kPoolStack) * ROWS * 64; }
+
+enum : uint32_t { PH_FREE = 0, PH_NODE = 1, PH_PACKET = 2, PH_SCALAR = 3, PH_EXIT = 4, PH_EMIT = 5 };
+
+// ctl word: sp[0:8) base[8:16) level[16:19) has_packets[19] kz[20:22) swap[22]
+__device__ __forceinline__ uint32_t ctl_pack(uint32_t sp, uint32_t base, uint32_t level, uint32_t hp, uint32_t kz,
+                                             uint32_t swap, uint32_t phase) {
+  return sp | (base << 8) | (level << 16) | (hp << 19) | (kz << 20) | (swap << 22) | (phase << 23);
+}
+__device__ __forceinline__ uint32_t ctl_phase(uint32_t c) { return (c >> 23) & 7u; }
+
+//   fetch(want, ray) -> bool : called by the whole wave; lanes with want==true may receive a ray
+//   emit(slot, hit?, Hit)    : called by a lane whose ray is finished (ANY: hit? means occluded)
+// t_min is uniform over the launch (every caller passes one value).
+//
+// LDS image of one wave (dwords, R = ROWS): [0, 4R*64) F0 = origin.xyz + closest (16 B per slot);
+// [4R*64, 8R*64) F1 = inv_dir.xyz + shear.x; then 2R*64 F2 = shear.y, shear.z (8 B per slot); then five dword
+// planes of R*64: ctl, cur, aux, cursor, mask; then the stack, kPoolStack planes. 60 + 4*kPoolStack bytes per ray.
+// The hit found so far (u, v, primitive, geometry) and the caller's slot tag are written once or twice per ray and
+// read at the end: they live in private memory with the other rarely used state.
+template <bool ANY, bool STATS, int ROWS, class Fetch, class Emit>
+__device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's pool_lds_dwords<ROWS>() */, float t_min,
+                              const uint32_t *lds_nodes /* staged top of the tree */, uint32_t n_lds, uint32_t &err,
+                              LaneStats &st, Fetch fetch, Emit emit) {
+  const int lane = threadIdx.x & 63;
+  constexpr int RL = ROWS * 64;
+  float4 *f0 = reinterpret_cast<float4 *>(lds);
+  float4 *f1 = reinterpret_cast<float4 *>(lds + 4 * RL);
+  float2 *f2 = reinterpret_cast<float2 *>(lds + 8 * RL);
+  uint32_t *w = lds + 10 * RL;  // dword planes
+  enum { W_CTL = 0, W_CUR, W_AUX, W_CURSOR, W_MASK };
+  enum { B_SLOT = 0, B_BU, B_BV, B_BDEFER, B_BGEOM };
+  uint32_t *stk = lds + 15 * RL;
+  auto at = [&](int row) { return row * 64 + lane; };
+  auto W = [&](int plane, int row) -> uint32_t & { return w[plane * RL + row * 64 + lane]; };
+  auto STK = [&](int e, int row) -> uint32_t & { return stk[e * RL + row * 64 + lane]; };
+
+  // rarely touched per-ray state, private memory indexed by row
+  float side_d[ROWS][4];   // direction in the current frame, shutter time
+  float side_n[ROWS][4];   // pending outward normal of a sphere / instanced hit, prim id (bits)
+  uint32_t best[ROWS][5];  // caller's slot tag; u, v (bits), pending triangle, geometry id of the closest hit so far
+  Frame frames[ROWS][kMaxLevels];
+  uint32_t spill[ROWS][kPoolSpill];
+
+  auto push = [&](int row, uint32_t &sp, uint32_t x) {
+    if (sp < (uint32_t)kPoolStack) STK((int)sp, row) = x;
+    else if (sp - kPoolStack < (uint32_t)kPoolSpill) spill[row][sp - kPoolStack] = x;
+    else { err |= 1u; return; }
+    sp++;
+  };
+  auto pop = [&](int row, uint32_t &sp) -> uint32_t {
+    sp--;
+    return sp < (uint32_t)kPoolStack ? STK((int)sp, row) : spill[row][sp - kPoolStack];
+  };
+  // What the ray does next: the rest of the leaf's scalar list, else the next stack entry, else leave the tree.
+  auto advance = [&](int row, uint32_t &sp, uint32_t base, uint32_t level, uint32_t rem, uint32_t &cur,
+                     uint32_t &cursor) -> uint32_t {
+    if (rem > 0) return PH_SCALAR;
+    for (;;) {
+      if (sp == base) return level > 0 ? PH_EXIT : PH_EMIT;
+      const uint32_t e = pop(row, sp);
+      if (e & kLeafTag) {
+        const uint32_t li = e & ~kLeafTag;
+        if (li == (kInvalid & ~kLeafTag)) continue;
+        cur = li;
+        cursor = 0;  // packet counter while in PH_PACKET
+        return PH_PACKET;
+      }
+      cur = e;
+      return PH_NODE;
+    }
+  };
+  auto unpack_k = [&](uint32_t c, int &kx, int &ky, int &kz) {
+    kz = (int)((c >> 20) & 3u);
+    kx = kz == 2 ? 0 : kz + 1;
+    ky = kx == 2 ? 0 : kx + 1;
+    if ((c >> 22) & 1u) { const int t = kx; kx = ky; ky = t; }
+  };
+  // (re)derive the per-tree ray constants from origin + direction and store them (closest is passed through)
+  auto store_ray = [&](int row, RayCtx &r, bool with_shear, float closest, uint32_t &kz_out, uint32_t &swap_out) {
+    r.kx = 0; r.ky = 1; r.kz = 2; r.sx = r.sy = r.sz = 0.0f;
+    setup_ray(r, with_shear);
+    kz_out = (uint32_t)r.kz;
+    const int kx0 = r.kz == 2 ? 0 : r.kz + 1;
+    swap_out = (r.kx != kx0) ? 1u : 0u;
+    f0[at(row)] = make_float4(r.ox, r.oy, r.oz, closest);
+    f1[at(row)] = make_float4(r.ix, r.iy, r.iz, r.sx);
+    f2[at(row)] = make_float2(r.sy, r.sz);
+  };
+
+  uint32_t ph[ROWS];  // phase of this lane's slots: only this lane ever changes them, so they live in registers
+#pragma unroll
+  for (int row = 0; row < ROWS; row++) ph[row] = PH_FREE;
+  bool more = true;  // wave-uniform: the source may still hold rays
+  unsigned long long t_mark = STATS ? (unsigned long long)clock64() : 0ull;
+  auto lap = [&](int k) {  // STATS: charge the cycles since the last mark to phase k
+    if (STATS) {
+      const unsigned long long now = (unsigned long long)clock64();
+      st.ph_cyc[k] += now - t_mark;
+      t_mark = now;
+    }
+  };
+
+  for (;;) {
+    uint32_t have = 0;  // bit q: this lane has a slot in phase q
+#pragma unroll
+    for (int row = 0; row < ROWS; row++) have |= 1u << ph[row];
+    const int n_free = __popcll(__ballot(have & (1u << PH_FREE)));
+    if (more && n_free >= kFetchMin) {
+      // ---- fetch + setup ----
+      lap(0);
+      const bool want = (have & (1u << PH_FREE)) != 0;
+      RayIn in;
+      const bool got = fetch(want, in);
+      if (got) {
+        CRT_PHASE(1)
+        int row = 0;
+#pragma unroll
+        for (int k = ROWS - 1; k >= 0; k--)
+          if (ph[k] == PH_FREE) row = k;
+        RayCtx r;
+        r.ox = in.ox; r.oy = in.oy; r.oz = in.oz; r.dx = in.dx; r.dy = in.dy; r.dz = in.dz;
+        uint32_t kz, swap;
+        store_ray(row, r, S.has_packets != 0, in.t_max, kz, swap);
+        const bool empty = S.root == kInvalid;  // bvh.rs:442-444
+        const uint32_t first = empty ? PH_EMIT : PH_NODE;
+        W(W_CTL, row) = ctl_pack(0, 0, 0, S.has_packets ? 1u : 0u, kz, swap, 0);
+        W(W_CUR, row) = S.root;
+        W(W_AUX, row) = 0; W(W_CURSOR, row) = 0; W(W_MASK, row) = in.mask; best[row][B_SLOT] = in.slot;
+        best[row][B_BU] = 0; best[row][B_BV] = 0; best[row][B_BDEFER] = kInvalid; best[row][B_BGEOM] = kInvalid;
+        side_d[row][0] = in.dx; side_d[row][1] = in.dy; side_d[row][2] = in.dz; side_d[row][3] = in.time;
+#pragma unroll
+        for (int k = 0; k < ROWS; k++)
+          if (k == row) ph[k] = first;
+        if (STATS) st.queries[0]++;
+      }
+      if (__ballot(want && !got)) more = false;  // a lane asked and got nothing: the source is dry
+      lap(1);
+      continue;
+    }
+
+    // ---- pick the phase to run: a rare one once enough lanes wait for it, else the busier of node / packet ----
+    const int n_node = __popcll(__ballot(have & (1u << PH_NODE)));
+    const int n_pkt = __popcll(__ballot(have & (1u << PH_PACKET)));
+    const int n_sc = __popcll(__ballot(have & (1u << PH_SCALAR)));
+    const int n_exit = __popcll(__ballot(have & (1u << PH_EXIT)));
+    const int n_emit = __popcll(__ballot(have & (1u << PH_EMIT)));
+    uint32_t q;
+    {
+      int best_rare = n_sc;
+      uint32_t q_rare = PH_SCALAR;
+      if (n_exit > best_rare) { best_rare = n_exit; q_rare = PH_EXIT; }
+      if (n_emit > best_rare) { best_rare = n_emit; q_rare = PH_EMIT; }
+      if (best_rare >= kRareMin) q = q_rare;
+      else if (n_node + n_pkt > 0) q = n_node >= n_pkt ? PH_NODE : PH_PACKET;
+      else if (best_rare > 0) q = q_rare;
+      else break;  // every slot is free (and the source is dry, or the fetch above would have run)
+    }
+    const bool mine = (have & (1u << q)) != 0;
+    int row = 0;
+#pragma unroll
+    for (int k = ROWS - 1; k >= 0; k--)
+      if (ph[k] == q) row = k;
+    uint32_t next = q;  // phase of slot `row` after this step (meaningful for lanes with `mine`)
+    if (mine) { CRT_PHASE(0) }
+    lap(0);
+
+    if (q == PH_NODE) {
+      // ================= node expansion (bvh.rs:455-505), repeated while most of the lanes stay in it =================
+      float4 g0 = make_float4(0, 0, 0, 0), g1 = g0;
+      uint32_t c = 0, sp = 0, base = 0, level = 0, cur = 0, cursor = 0;
+      if (mine) {
+        g0 = f0[at(row)]; g1 = f1[at(row)];
+        c = W(W_CTL, row); cur = W(W_CUR, row);
+        sp = c & 0xffu; base = (c >> 8) & 0xffu; level = (c >> 16) & 7u;
+      }
+      bool act = mine;
+      for (;;) {
+        if (act) {
+          CRT_PHASE(2)
+          const float closest = g0.w;
+          if (STATS) st.nodes[level > 0 ? 1 : 0]++;
+          float4 mnx, mny, mnz, mxx, mxy, mxz;
+          uint4 ch;
+          uint32_t flags;
+          if (cur < n_lds) {  // top of the tree: LDS (ds_read_b128), no trip through the vector memory pipeline
+            const float4 *nb = reinterpret_cast<const float4 *>(lds_nodes + (size_t)cur * kLdsNodeStride);
+            mnx = nb[0]; mny = nb[1]; mnz = nb[2]; mxx = nb[3]; mxy = nb[4]; mxz = nb[5];
+            ch = *reinterpret_cast<const uint4 *>(nb + 6);
+            flags = lds_nodes[(size_t)cur * kLdsNodeStride + 28];
+          } else {
+            const WideNode *nd = &S.nodes[cur];
+            const float4 *nb = reinterpret_cast<const float4 *>(nd);
+            mnx = nb[0]; mny = nb[1]; mnz = nb[2]; mxx = nb[3]; mxy = nb[4]; mxz = nb[5];
+            ch = *reinterpret_cast<const uint4 *>(nd->child);
+            flags = nd->flags;
+          }
+          const float lo_x[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, lo_y[4] = {mny.x, mny.y, mny.z, mny.w},
+                      lo_z[4] = {mnz.x, mnz.y, mnz.z, mnz.w};
+          const float hi_x[4] = {mxx.x, mxx.y, mxx.z, mxx.w}, hi_y[4] = {mxy.x, mxy.y, mxy.z, mxy.w},
+                      hi_z[4] = {mxz.x, mxz.y, mxz.z, mxz.w};
+          const uint32_t child[4] = {ch.x, ch.y, ch.z, ch.w};
+          float key[4];
+          uint32_t ent[4];
+#pragma unroll
+          for (int l = 0; l < 4; l++) {  // RaySlab::slab4, bvh.rs:790-808
+            const float t0x = (lo_x[l] - g0.x) * g1.x, t1x = (hi_x[l] - g0.x) * g1.x;
+            const float t0y = (lo_y[l] - g0.y) * g1.y, t1y = (hi_y[l] - g0.y) * g1.y;
+            const float t0z = (lo_z[l] - g0.z) * g1.z, t1z = (hi_z[l] - g0.z) * g1.z;
+            const float tn = fmaxf(fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z)), t_min);
+            const float tf = fminf(fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)), closest);
+            const bool on = (tn <= tf) && ((flags >> l) & 1u);
+            key[l] = tn;
+            ent[l] = on ? (child[l] | (((flags >> (4 + l)) & 1u) ? kLeafTag : 0u)) : kInvalid;  // kInvalid = lane off
+          }
+          if (!ANY) {
+            // Stable insertion sort of the hit lanes by entry distance (bvh.rs:472-486); off lanes sort last.
+#pragma unroll
+            for (int l = 0; l < 4; l++)
+              if (ent[l] == kInvalid) key[l] = __builtin_inff();
+            auto after = [&](int a, int b) {
+              const bool offa = ent[a] == kInvalid, offb = ent[b] == kInvalid;
+              return (key[a] > key[b]) || (key[a] == key[b] && offa && !offb);
+            };
+            auto swp = [&](int a, int b) {
+              const float k = key[a]; key[a] = key[b]; key[b] = k;
+              const uint32_t x = ent[a]; ent[a] = ent[b]; ent[b] = x;
+            };
+            if (after(0, 1)) swp(0, 1);
+            if (after(1, 2)) { swp(1, 2); if (after(0, 1)) swp(0, 1); }
+            if (after(2, 3)) { swp(2, 3); if (after(1, 2)) { swp(1, 2); if (after(0, 1)) swp(0, 1); } }
+          }
+          // Stack image after this node, bottom to top. Ordered traversal: inner lanes far to near, then leaf
+          // lanes far to near on top, so they pop first and near-first — the reference's "leaf lanes now, near
+          // first; inner lanes pushed far to near" (bvh.rs:488-505). Any-hit: the hit lanes in lane order
+          // (bvh.rs:596-606). Every entry's final position is known up front, so the entries are stored with
+          // independent predicated writes, and the top one — the entry the ray visits next — stays in a register.
+          uint32_t on[4], lf4[4], pos[4];
+#pragma unroll
+          for (int i = 0; i < 4; i++) { on[i] = ent[i] != kInvalid ? 1u : 0u; lf4[i] = (on[i] && (ent[i] & kLeafTag)) ? 1u : 0u; }
+          uint32_t n_tot;
+          if (ANY) {
+            pos[0] = 0; pos[1] = on[0]; pos[2] = on[0] + on[1]; pos[3] = on[0] + on[1] + on[2];
+            n_tot = pos[3] + on[3];
+          } else {
+            const uint32_t in0 = on[0] - lf4[0], in1 = on[1] - lf4[1], in2 = on[2] - lf4[2], in3 = on[3] - lf4[3];
+            const uint32_t n_in = in0 + in1 + in2 + in3;
+            // entries are sorted near (0) to far (3); an entry sits above every farther entry of its kind
+            pos[3] = lf4[3] ? n_in : 0u;
+            pos[2] = lf4[2] ? n_in + lf4[3] : in3;
+            pos[1] = lf4[1] ? n_in + lf4[3] + lf4[2] : in3 + in2;
+            pos[0] = lf4[0] ? n_in + lf4[3] + lf4[2] + lf4[1] : in3 + in2 + in1;
+            n_tot = n_in + lf4[0] + lf4[1] + lf4[2] + lf4[3];
+          }
+          if (n_tot == 0) {
+            next = advance(row, sp, base, level, 0, cur, cursor);
+          } else {
+            uint32_t top_e = 0;
+            if (sp + n_tot - 1 <= (uint32_t)kPoolStack) {  // the stored entries fit the LDS part of the stack
+#pragma unroll
+              for (int i = 0; i < 4; i++) {
+                if (on[i]) {
+                  if (pos[i] == n_tot - 1) top_e = ent[i];
+                  else STK((int)(sp + pos[i]), row) = ent[i];
+                }
+              }
+              sp += n_tot - 1;
+            } else {  // deep stack: one entry at a time through the spill path
+              for (uint32_t k = 0; k < n_tot; k++) {
+                uint32_t e = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                  if (on[i] && pos[i] == k) e = ent[i];
+                if (k == n_tot - 1) top_e = e;
+                else push(row, sp, e);
+              }
+            }
+            if (top_e & kLeafTag) {
+              const uint32_t li = top_e & ~kLeafTag;
+              if (li == (kInvalid & ~kLeafTag)) next = advance(row, sp, base, level, 0, cur, cursor);
+              else { cur = li; cursor = 0; next = PH_PACKET; }
+            } else {
+              cur = top_e;
+              next = PH_NODE;
+            }
+          }
+          act = next == PH_NODE;
+        }
+        if (__popcll(__ballot(act)) < kStickyMin) break;  // wave-uniform
+      }
+      if (mine) {
+        W(W_CTL, row) = (c & ~0xffu) | sp;
+        W(W_CUR, row) = cur;
+        if (next == PH_PACKET) W(W_CURSOR, row) = 0;
+      }
+    } else if (q == PH_PACKET) {
+      // ============ Tri4 packets of the current leaf (bvh.rs:514-562, triangle.rs:276-348), one per turn ============
+      float4 g0 = make_float4(0, 0, 0, 0), g1 = g0;
+      float2 g2 = make_float2(0, 0);
+      uint32_t c = 0, sp = 0, base = 0, level = 0, cur = 0, k = 0, aux = 0, rmask = 0;
+      if (mine) {
+        g0 = f0[at(row)]; g1 = f1[at(row)]; g2 = f2[at(row)];
+        c = W(W_CTL, row); cur = W(W_CUR, row); k = W(W_CURSOR, row); aux = W(W_AUX, row); rmask = W(W_MASK, row);
+        sp = c & 0xffu; base = (c >> 8) & 0xffu; level = (c >> 16) & 7u;
+      }
+      int kx, ky, kz;
+      unpack_k(c, kx, ky, kz);
+      float closest = g0.w;
+      float bu = 0.0f, bv = 0.0f;
+      uint32_t bdefer = kInvalid;
+      bool accepted = false, occluded = false;
+      uint32_t cursor = 0, rem = 0;
+      bool act = mine;
+      for (;;) {
+        if (act) {
+          const Leaf lf = S.leaves[cur];
+          const int sl = level > 0 ? 1 : 0;
+          if (STATS && k == 0) { st.leaves[sl]++; st.packets[sl] += lf.pkt_count; st.prims[sl] += lf.idx_count; }
+          if (k < lf.pkt_count) {
+            const Tri4 *pk = &S.packets[lf.pkt_first + k];
+            const uint4 meta = *reinterpret_cast<const uint4 *>(&pk->active);  // active, mask_and, mask_or, masks[0]
+            uint32_t m;                                                         // triangle.rs:257-271
+            if (rmask & meta.y) m = meta.x;
+            else if ((rmask & meta.z) == 0) m = 0;
+            else {
+              m = 0;
+#pragma unroll
+              for (int l = 0; l < 4; l++)
+                if ((meta.x & (1u << l)) && (pk->masks[l] & rmask)) m |= 1u << l;
+            }
+            if (m != 0) {
+              CRT_PHASE(3)
+              RayCtx r;
+              r.ox = g0.x; r.oy = g0.y; r.oz = g0.z;
+              r.kx = kx; r.ky = ky; r.kz = kz; r.sx = g1.w; r.sy = g2.x; r.sz = g2.y;
+              r.okx = sel3(g0.x, g0.y, g0.z, kx); r.oky = sel3(g0.x, g0.y, g0.z, ky); r.okz = sel3(g0.x, g0.y, g0.z, kz);
+              const float4 *pl = reinterpret_cast<const float4 *>(&pk->v[0][0][0]);
+              const float4 A_x = pl[0 + kx], A_y = pl[0 + ky], A_z = pl[0 + kz];
+              const float4 B_x = pl[3 + kx], B_y = pl[3 + ky], B_z = pl[3 + kz];
+              const float4 C_x = pl[6 + kx], C_y = pl[6 + ky], C_z = pl[6 + kz];
+              const float vax[4] = {A_x.x, A_x.y, A_x.z, A_x.w}, vay[4] = {A_y.x, A_y.y, A_y.z, A_y.w},
+                          vaz[4] = {A_z.x, A_z.y, A_z.z, A_z.w};
+              const float vbx[4] = {B_x.x, B_x.y, B_x.z, B_x.w}, vby[4] = {B_y.x, B_y.y, B_y.z, B_y.w},
+                          vbz[4] = {B_z.x, B_z.y, B_z.z, B_z.w};
+              const float vcx[4] = {C_x.x, C_x.y, C_x.z, C_x.w}, vcy[4] = {C_y.x, C_y.y, C_y.z, C_y.w},
+                          vcz[4] = {C_z.x, C_z.y, C_z.z, C_z.w};
+              uint32_t fallback = 0, hits = 0;
+              float ht[4], hu[4], hv[4];
+              const float entry_closest = closest;  // every lane range-tests against the packet-entry bound
+#pragma unroll
+              for (int l = 0; l < 4; l++) {  // triangle.rs:284-347, one SIMD lane at a time
+                const float akz = vaz[l] - r.okz, bkz = vbz[l] - r.okz, ckz = vcz[l] - r.okz;
+                const float ax = (vax[l] - r.okx) - r.sx * akz, ay = (vay[l] - r.oky) - r.sy * akz;
+                const float bx = (vbx[l] - r.okx) - r.sx * bkz, by = (vby[l] - r.oky) - r.sy * bkz;
+                const float cx = (vcx[l] - r.okx) - r.sx * ckz, cy = (vcy[l] - r.oky) - r.sy * ckz;
+                const float e0 = bx * cy - by * cx;
+                const float e1 = cx * ay - cy * ax;
+                const float e2 = ax * by - ay * bx;
+                const bool zero = (e0 == 0.0f) | (e1 == 0.0f) | (e2 == 0.0f);
+                const bool neg = (e0 < 0.0f) | (e1 < 0.0f) | (e2 < 0.0f);
+                const bool pos = (e0 > 0.0f) | (e1 > 0.0f) | (e2 > 0.0f);
+                const float det = e0 + e1 + e2;
+                const float t_scaled = e0 * (r.sz * akz) + e1 * (r.sz * bkz) + e2 * (r.sz * ckz);
+                const float abs_det = absf(det);
+                const float ts = det < 0.0f ? -t_scaled : t_scaled;
+                const bool in_range = (ts >= t_min * abs_det) & (ts <= entry_closest * abs_det);
+                const bool lane_on = (m >> l) & 1u;
+                if (lane_on && zero) fallback |= 1u << l;
+                if (lane_on && !zero && !(neg && pos) && det != 0.0f && in_range) hits |= 1u << l;
+                const float inv_det = 1.0f / det;
+                ht[l] = t_scaled * inv_det;
+                hu[l] = e1 * inv_det;
+                hv[l] = e2 * inv_det;
+              }
+              if (ANY) {
+                if (hits) occluded = true;
+              } else {
+#pragma unroll
+                for (int l = 0; l < 4; l++) {  // bvh.rs:533-550
+                  if (!((hits >> l) & 1u)) continue;
+                  if (ht[l] > closest) continue;               // strict: an exact tie goes to the later lane
+                  if (!((pk->normal_ok >> l) & 1u)) continue;  // prim.rs:81-83 degenerate sliver
+                  closest = ht[l]; bu = hu[l]; bv = hv[l];
+                  bdefer = pk->prim[l];
+                  accepted = true;
+                  if (STATS) st.accepted++;
+                }
+              }
+              if (fallback && !occluded) {  // bvh.rs:551-561 / :636-643 — lanes sitting exactly on an edge
+#pragma unroll
+                for (int l = 0; l < 4; l++) {
+                  if (!((fallback >> l) & 1u)) continue;
+                  const uint32_t pi = pk->prim[l];
+                  const DevPrim *p = &S.prims[pi];
+                  if ((rmask & p->mask) == 0) continue;
+                  CRT_PHASE(7)
+                  float t, u, v;
+                  if (!tri_scalar(r, p->d, t_min, closest, t, u, v)) continue;
+                  if (ANY) { occluded = true; break; }
+                  if (!((pk->normal_ok >> l) & 1u)) continue;
+                  closest = t; bu = u; bv = v; bdefer = pi;
+                  accepted = true;
+                  if (STATS) st.accepted++;
+                }
+              }
+            }
+            k++;
+          }
+          if (occluded) {
+            next = PH_EMIT;
+            act = false;
+          } else if (k < lf.pkt_count) {
+            next = PH_PACKET;  // act stays true: the leaf has another packet
+          } else {
+            cursor = lf.idx_first;
+            rem = lf.idx_count;
+            next = PH_SCALAR;  // resolved below, once, after the run
+            act = false;
+          }
+        }
+        if (__popcll(__ballot(act)) < kStickyMin) break;  // wave-uniform
+      }
+      if (mine) {
+        if (accepted) {
+          f0[at(row)].w = closest;
+          best[row][B_BU] = __float_as_uint(bu); best[row][B_BV] = __float_as_uint(bv); best[row][B_BDEFER] = bdefer;
+          aux |= 1u << level;
+        }
+        if (occluded) aux |= 1u;
+        if (next == PH_PACKET) {
+          cursor = k;
+        } else if (next == PH_SCALAR) {  // the leaf's packets are done: scalar list, or on to the next entry
+          aux = (aux & 0xffu) | (rem << 8);
+          next = advance(row, sp, base, level, rem, cur, cursor);
+        }
+        W(W_CTL, row) = (c & ~0xffu) | sp;
+        W(W_CUR, row) = cur;
+        W(W_CURSOR, row) = cursor;
+        W(W_AUX, row) = aux;
+      }
+    } else if (q == PH_SCALAR) {
+      // ================= one primitive of the leaf's scalar list (bvh.rs:564-570 / :646-651) =================
+      if (mine) {
+        CRT_PHASE(4)
+        const float4 g0 = f0[at(row)];
+        uint32_t c = W(W_CTL, row);
+        uint32_t sp = c & 0xffu;
+        uint32_t base = (c >> 8) & 0xffu, level = (c >> 16) & 7u;
+        const uint32_t hp = (c >> 19) & 1u;
+        uint32_t cur = W(W_CUR, row);
+        uint32_t cursor = W(W_CURSOR, row);
+        uint32_t aux = W(W_AUX, row);
+        const uint32_t rmask = W(W_MASK, row);
+        uint32_t rem = (aux >> 8) & 0xffu;
+        float closest = g0.w;
+        const float dx = side_d[row][0], dy = side_d[row][1], dz = side_d[row][2], time = side_d[row][3];
+        const uint32_t pi = S.indices[cursor];
+        cursor++;
+        rem--;
+        const DevPrim *p = &S.prims[pi];
+        const uint4 hd = *reinterpret_cast<const uint4 *>(p);  // kind, geom_id, prim_id, mask
+        bool occluded = false;
+        if ((rmask & hd.w) != 0) {  // prim.rs:52-54
+          if (hd.x == PRIM_SPHERE) {  // prim.rs:133-161
+            const float4 s = *reinterpret_cast<const float4 *>(p->d);
+            const float ocx = g0.x - s.x, ocy = g0.y - s.y, ocz = g0.z - s.z;
+            const float a = dot3(dx, dy, dz, dx, dy, dz);
+            const float half_b = dot3(ocx, ocy, ocz, dx, dy, dz);
+            const float cc = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - s.w * s.w;
+            const float disc = half_b * half_b - a * cc;
+            if (!(disc < 0.0f)) {
+              const float sqrt_d = sqrtf(disc);
+              float root = (-half_b - sqrt_d) / a;
+              bool ok = true;
+              if (root <= t_min || root >= closest) {
+                root = (-half_b + sqrt_d) / a;
+                if (root <= t_min || root >= closest) ok = false;
+              }
+              if (ok) {
+                if (ANY) occluded = true;
+                else {
+                  closest = root;
+                  f0[at(row)].w = root;
+                  side_n[row][0] = ((g0.x + root * dx) - s.x) / s.w;
+                  side_n[row][1] = ((g0.y + root * dy) - s.y) / s.w;
+                  side_n[row][2] = ((g0.z + root * dz) - s.z) / s.w;
+                  side_n[row][3] = __uint_as_float(0u);  // prim_id 0
+                  best[row][B_BU] = 0; best[row][B_BV] = 0; best[row][B_BDEFER] = kInvalid; best[row][B_BGEOM] = hd.y;
+                  aux |= 1u << level;
+                  if (STATS) st.accepted++;
+                }
+              }
+            }
+          } else if (hd.x == PRIM_INSTANCE) {  // prim.rs:345-378
+            if (level + 1 >= (uint32_t)kMaxLevels) err |= 2u;
+            else {
+              const uint32_t inst = __float_as_uint(p->d[0]);
+              const DevInstance *in = &S.instances[inst];
+              float w2l[12];
+              if (in->has_end && time > 0.0f) motion_w2l(*in, time, w2l);
+              else {
+#pragma unroll
+                for (int i = 0; i < 12; i++) w2l[i] = in->w2l[i];
+              }
+              Frame &f = frames[row][level];
+              f.ox = g0.x; f.oy = g0.y; f.oz = g0.z; f.dx = dx; f.dy = dy; f.dz = dz;
+              f.cursor = cursor; f.cend = rem; f.base = base; f.inst = inst; f.geom = hd.y; f.has_packets = hp;
+              // transform_point3a / transform_vector3a: ((x_axis*v.x + y_axis*v.y) + z_axis*v.z) [+ translation]
+              float px = w2l[0] * g0.x, py = w2l[1] * g0.x, pz = w2l[2] * g0.x;
+              px = px + w2l[3] * g0.y; py = py + w2l[4] * g0.y; pz = pz + w2l[5] * g0.y;
+              px = px + w2l[6] * g0.z; py = py + w2l[7] * g0.z; pz = pz + w2l[8] * g0.z;
+              px = px + w2l[9]; py = py + w2l[10]; pz = pz + w2l[11];
+              float qx = w2l[0] * dx, qy = w2l[1] * dx, qz = w2l[2] * dx;
+              qx = qx + w2l[3] * dy; qy = qy + w2l[4] * dy; qz = qz + w2l[5] * dy;
+              qx = qx + w2l[6] * dz; qy = qy + w2l[7] * dz; qz = qz + w2l[8] * dz;
+              RayCtx r;
+              r.ox = px; r.oy = py; r.oz = pz; r.dx = qx; r.dy = qy; r.dz = qz;  // unnormalised: local t == world t
+              side_d[row][0] = qx; side_d[row][1] = qy; side_d[row][2] = qz;
+              level++;
+              aux &= ~(1u << level);
+              base = sp;
+              cursor = 0;
+              rem = 0;
+              uint32_t kz, swap;
+              store_ray(row, r, in->has_packets != 0, closest, kz, swap);
+              c = ctl_pack(sp, base, level, in->has_packets ? 1u : 0u, kz, swap, 0);
+              if (STATS) { st.descents++; st.queries[1]++; }
+              push(row, sp, in->root);
+            }
+          } else {
+            // A triangle on the scalar list (the builder always packs triangles; kept for completeness).
+            RayCtx rr;
+            rr.ox = g0.x; rr.oy = g0.y; rr.oz = g0.z; rr.dx = dx; rr.dy = dy; rr.dz = dz;
+            setup_ray(rr, true);
+            float t, u, v;
+            if (tri_scalar(rr, p->d, t_min, closest, t, u, v)) {
+              if (ANY) occluded = true;
+              else {
+                const float e1x = p->d[3] - p->d[0], e1y = p->d[4] - p->d[1], e1z = p->d[5] - p->d[2];
+                const float e2x = p->d[6] - p->d[0], e2y = p->d[7] - p->d[1], e2z = p->d[8] - p->d[2];
+                const bool flat = (e1y * e2z - e2y * e1z) == 0.0f && (e1z * e2x - e2z * e1x) == 0.0f &&
+                                  (e1x * e2y - e2x * e1y) == 0.0f;
+                if (!(flat && __float_as_uint(p->d[9]) == kInvalid)) {
+                  closest = t;
+                  f0[at(row)].w = t;
+                  best[row][B_BU] = __float_as_uint(u); best[row][B_BV] = __float_as_uint(v); best[row][B_BDEFER] = pi;
+                  aux |= 1u << level;
+                  if (STATS) st.accepted++;
+                }
+              }
+            }
+          }
+        }
+        if (occluded) { aux |= 1u; next = PH_EMIT; }
+        else next = advance(row, sp, base, level, rem, cur, cursor);
+        aux = (aux & 0xffu) | (rem << 8);
+        W(W_CTL, row) = (c & ~0xffffu) | sp | (base << 8);
+        W(W_CUR, row) = cur;
+        W(W_CURSOR, row) = cursor;
+        W(W_AUX, row) = aux;
+      }
+    } else if (q == PH_EXIT) {
+      // ============ the instanced tree is exhausted: back to the parent frame (prim.rs:358-364) ============
+      if (mine) {
+        CRT_PHASE(5)
+        const uint32_t c = W(W_CTL, row);
+        uint32_t sp = c & 0xffu;
+        uint32_t level = (c >> 16) & 7u;
+        uint32_t aux = W(W_AUX, row);
+        uint32_t cur = W(W_CUR, row);
+        const float closest = f0[at(row)].w;
+        const float time = side_d[row][3];
+        const bool inner_found = (aux >> level) & 1u;
+        level--;
+        const Frame f = frames[row][level];
+        if (inner_found) {
+          float bnx, bny, bnz;
+          uint32_t bprim;
+          const uint32_t bdefer = best[row][B_BDEFER];
+          if (bdefer != kInvalid) {
+            tri_normal(S, bdefer, __uint_as_float(best[row][B_BU]), __uint_as_float(best[row][B_BV]), bnx, bny, bnz);
+            bprim = S.prims[bdefer].prim_id;
+          } else {
+            bnx = side_n[row][0]; bny = side_n[row][1]; bnz = side_n[row][2];
+            bprim = __float_as_uint(side_n[row][3]);
+          }
+          const DevInstance *in = &S.instances[f.inst];
+          float nm[9];
+          if (in->has_end && time > 0.0f) {
+            float w2l[12];
+            motion_w2l(*in, time, w2l);
+            // normal matrix = w2l.matrix3 transposed (prim.rs:327)
+            nm[0] = w2l[0]; nm[1] = w2l[3]; nm[2] = w2l[6];
+            nm[3] = w2l[1]; nm[4] = w2l[4]; nm[5] = w2l[7];
+            nm[6] = w2l[2]; nm[7] = w2l[5]; nm[8] = w2l[8];
+          } else {
+#pragma unroll
+            for (int i = 0; i < 9; i++) nm[i] = in->nmat[i];
+          }
+          float x = nm[0] * bnx, y = nm[1] * bnx, z = nm[2] * bnx;
+          x = x + nm[3] * bny; y = y + nm[4] * bny; z = z + nm[5] * bny;
+          x = x + nm[6] * bnz; y = y + nm[7] * bnz; z = z + nm[8] * bnz;
+          const float len = sqrtf(dot3(x, y, z, x, y, z));
+          side_n[row][0] = x / len; side_n[row][1] = y / len; side_n[row][2] = z / len;
+          side_n[row][3] = __uint_as_float(bprim);
+          // the hit is attributed to the instance's geometry id; prim_id stays the inner one
+          best[row][B_BDEFER] = kInvalid; best[row][B_BGEOM] = f.geom;
+          aux |= 1u << level;
+          if (STATS) st.accepted++;
+        }
+        RayCtx r;
+        r.ox = f.ox; r.oy = f.oy; r.oz = f.oz; r.dx = f.dx; r.dy = f.dy; r.dz = f.dz;
+        side_d[row][0] = f.dx; side_d[row][1] = f.dy; side_d[row][2] = f.dz;
+        uint32_t kz, swap;
+        store_ray(row, r, f.has_packets != 0, closest, kz, swap);
+        uint32_t cursor = f.cursor;
+        const uint32_t rem = f.cend;
+        next = advance(row, sp, f.base, level, rem, cur, cursor);
+        W(W_CTL, row) = ctl_pack(sp, f.base, level, f.has_packets ? 1u : 0u, kz, swap, 0);
+        W(W_CUR, row) = cur;
+        W(W_CURSOR, row) = cursor;
+        W(W_AUX, row) = (aux & 0xffu) | (rem << 8);
+      }
+    } else {
+      // ================= emit: the ray is finished =================
+      if (mine) {
+        CRT_PHASE(6)
+        const uint32_t aux = W(W_AUX, row);
+        const uint32_t slot = best[row][B_SLOT];
+        const bool is_hit = (aux & 1u) != 0;
+        Hit hit;
+        hit.t = 0.0f; hit.u = 0.0f; hit.v = 0.0f; hit.nx = hit.ny = hit.nz = 0.0f; hit.geom = kInvalid; hit.prim = kInvalid;
+        if (!ANY && is_hit) {
+          hit.t = f0[at(row)].w;
+          hit.u = __uint_as_float(best[row][B_BU]); hit.v = __uint_as_float(best[row][B_BV]);
+          const uint32_t bdefer = best[row][B_BDEFER];
+          if (bdefer != kInvalid) {
+            tri_normal(S, bdefer, hit.u, hit.v, hit.nx, hit.ny, hit.nz);
+            const DevPrim *p = &S.prims[bdefer];
+            hit.geom = p->geom_id; hit.prim = p->prim_id;
+          } else {
+            hit.nx = side_n[row][0]; hit.ny = side_n[row][1]; hit.nz = side_n[row][2];
+            hit.geom = best[row][B_BGEOM]; hit.prim = __float_as_uint(side_n[row][3]);
+          }
+        }
+        emit(slot, is_hit, hit);
+        next = PH_FREE;
+      }
+    }
+    if (mine) {
+#pragma unroll
+      for (int k = 0; k < ROWS; k++)
+        if (k == row) ph[k] = next;
+    }
+    lap(q == PH_NODE ? 2 : q == PH_PACKET ? 3 : q == PH_SCALAR ? 4 : q == PH_EXIT ? 5 : 6);
+  }
+}
+
+// ---- engine selection: CRT_POOL_ROWS rays per lane, phase-scheduled (default 2); 0 = one ray per lane (traverse.hip.h) ----
+#ifndef CRT_POOL_ROWS
+#define CRT_POOL_ROWS 2
+#endif
+#ifndef CRT_POOL_NODES
+#define CRT_POOL_NODES 32
+#endif
+#if CRT_POOL_ROWS > 0
+constexpr int kPoolNodes = CRT_POOL_NODES;  // nodes of the top of the tree staged in LDS per workgroup
+constexpr int kEngineLdsDwords = (kBlock / 64) * pool_lds_dwords<CRT_POOL_ROWS>() + kPoolNodes * kLdsNodeStride;
+#else
+constexpr int kEngineLdsDwords = kStackLds * kBlock + kLdsNodes * kLdsNodeStride;
+#endif
+// Runs the selected engine for one workgroup. `lds` = kEngineLdsDwords dwords, 16-byte aligned. Contains a
+// workgroup barrier: call from uniform control flow, after shared variables the callbacks use are initialised.
+template <bool ANY, bool STATS, class Fetch, class Emit>
+__device__ __forceinline__ void run_traversal(const DevScene &S, uint32_t *lds, float t_min, uint32_t &err, LaneStats &st,
+                                              Fetch fetch, Emit emit) {
+#if CRT_POOL_ROWS > 0
+  uint32_t *lds_nodes = lds + (kBlock / 64) * pool_lds_dwords<CRT_POOL_ROWS>();
+  const uint32_t n_lds = stage_nodes(S, lds_nodes, kPoolNodes);  // ends with a barrier
+  traverse_pool<ANY, STATS, CRT_POOL_ROWS>(S, lds + (threadIdx.x >> 6) * pool_lds_dwords<CRT_POOL_ROWS>(), t_min, lds_nodes,
+                                           n_lds, err, st, fetch, emit);
+#else
+  uint32_t *lds_nodes = lds + kStackLds * kBlock;
+  const uint32_t n_lds = stage_nodes(S, lds_nodes);  // ends with a barrier
+  traverse_stream<ANY, STATS>(S, lds + threadIdx.x, lds_nodes, n_lds, err, st, fetch, emit);
+#endif
+}
+
+}  // namespace dev
+}  // namespace crt

@@ -73,6 +73,9 @@ typedef struct CrtTravStats {
    * fetch + setup, 2 node expansion, 3 packet test, 4 scalar-list primitive, 5 instance exit, 6 emit,
    * 7 on-edge f64 fallback. */
   uint64_t phase_waves[8], phase_lanes[8];
+  /* Shader-clock cycles the waves spent in each phase (summed over waves; phase 0 = scheduling between phases).
+   * Filled by the phase-scheduled engine only. */
+  uint64_t phase_cycles[8];
 } CrtTravStats;
 
 typedef struct CrtBuilder CrtBuilder; /* crust_rt::SceneBuilder (scene.rs:147-149) */

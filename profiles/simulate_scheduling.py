@@ -98,7 +98,54 @@ def sim_A(all_steps, refill=32):
     return instr, useful
 
 
-def sim_pool(all_tr, pool=128, lanes=64, rare_min=16, overhead=None):
+def sim_affine(all_tr, rows=2, rare_min=16, overhead=20, fetch_min=32):
+    """State in LDS but slot r is only ever processed by lane r % 64 (conflict-free LDS, no gather list): a lane
+    runs the chosen phase for at most one of its `rows` slots per step."""
+    instr = useful = 0
+    n = len(all_tr); nxt = 0
+    slots = [[None] * rows for _ in range(64)]
+    while True:
+        free = [(l, k) for l in range(64) for k in range(rows) if slots[l][k] is None]
+        live = [slots[l][k] for l in range(64) for k in range(rows) if slots[l][k] is not None]
+        lanes_free = len({l for l, _ in free})
+        if nxt < n and (lanes_free >= fetch_min or not live):
+            got = 0
+            seen = set()
+            for l, k in free:
+                if l in seen or nxt >= n:
+                    continue
+                seen.add(l); slots[l][k] = [all_tr[nxt], 0]; nxt += 1; got += 1
+            instr += COST["F"] + overhead; useful += COST["F"] * got
+            continue
+        if not live:
+            break
+        def ph_of(r):
+            return r[0][r[1]] if r[1] < len(r[0]) else "E"
+        cnt = {}
+        for l in range(64):
+            phs = {ph_of(r) for r in slots[l] if r is not None}
+            for p in phs:
+                cnt[p] = cnt.get(p, 0) + 1
+        common = {p: v for p, v in cnt.items() if p in "NP"}
+        rare = {p: v for p, v in cnt.items() if p not in "NP" and v >= rare_min}
+        cand = rare or common or cnt
+        ph = max(cand.items(), key=lambda kv: kv[1])[0]
+        k_run = 0
+        for l in range(64):
+            for k in range(rows):
+                r = slots[l][k]
+                if r is not None and ph_of(r) == ph:
+                    if ph == "E":
+                        slots[l][k] = None
+                    else:
+                        r[1] += 1
+                    k_run += 1
+                    break
+        instr += COST[ph] + overhead; useful += COST[ph] * k_run
+    return instr, useful
+
+
+def sim_pool(all_tr, pool=128, lanes=64, rare_min=16, overhead=None, fetch_min=64):
     """Pool of `pool` rays per wave; each iteration runs ONE phase for up to 64 rays in that phase. pool == 64
     with overhead 0 models policy B (register state, majority vote): a ray never changes lane."""
     overhead = COST["queue"] if overhead is None else overhead
@@ -107,7 +154,7 @@ def sim_pool(all_tr, pool=128, lanes=64, rare_min=16, overhead=None):
     nxt = 0
     live = []  # [trace, pos]
     while True:
-        if nxt < n and pool - len(live) >= min(lanes, n - nxt) and (pool - len(live) >= lanes or not live):
+        if nxt < n and pool - len(live) >= min(fetch_min, n - nxt) and (pool - len(live) >= fetch_min or not live):
             take = min(lanes, n - nxt, pool - len(live))
             for _ in range(take):
                 live.append([all_tr[nxt], 0]); nxt += 1
@@ -177,6 +224,15 @@ def main():
             ("C pool 96 in LDS", sim_pool(tr, pool=96)),
             ("C pool 128 in LDS", sim_pool(tr, pool=128)),
             ("C pool 192 in LDS", sim_pool(tr, pool=192)),
+            ("C pool 96, fetch>=32", sim_pool(tr, pool=96, fetch_min=32)),
+            ("C pool 96, fetch>=16", sim_pool(tr, pool=96, fetch_min=16)),
+            ("C pool 128, fetch>=32", sim_pool(tr, pool=128, fetch_min=32)),
+            ("C pool 128, fetch>=32, rare>=32", sim_pool(tr, pool=128, fetch_min=32, rare_min=32)),
+            ("C pool 128, fetch>=32, rare>=8", sim_pool(tr, pool=128, fetch_min=32, rare_min=8)),
+            ("C pool 160, fetch>=32", sim_pool(tr, pool=160, fetch_min=32)),
+            ("D lane-affine 2 rows", sim_affine(tr, rows=2)),
+            ("D lane-affine 3 rows", sim_affine(tr, rows=3)),
+            ("D lane-affine 4 rows", sim_affine(tr, rows=4)),
         ):
             print(f"   {name:28s} wave-instr/ray {ins / len(tr):7.2f}   lane utilisation {use / (64.0 * ins):5.3f}")
 
