@@ -172,6 +172,15 @@ __device__ __forceinline__ float pow_det(float x, float y) {
   if (x == CRT_INF) return y > 0.0f ? CRT_INF : 0.0f;
   return (float)exp_d((double)y * log_d((double)x));
 }
+__device__ __forceinline__ float exp_det(float x) { return (float)exp_d((double)x); }
+// ln(0) = -inf, ln(<0) = NaN like f32::ln
+__device__ __forceinline__ float log_det(float x) {
+  if (x != x) return x;
+  if (x == 0.0f) return -CRT_INF;
+  if (x < 0.0f) return __uint_as_float(0x7fc00000u);
+  if (x == CRT_INF) return x;
+  return (float)log_d((double)x);
+}
 __device__ __forceinline__ float pow2_(float x) { return x * x; }
 __device__ __forceinline__ float pow5_(float x) { const float x2 = x * x; const float x4 = x2 * x2; return x4 * x; }
 __device__ __forceinline__ float pow6_(float x) { const float x2 = x * x; const float x4 = x2 * x2; return x4 * x2; }

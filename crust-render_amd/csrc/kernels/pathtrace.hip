@@ -47,11 +47,13 @@ namespace {
 #endif
 
 enum { K_CAMERA = 0, K_PATH = 1, K_TIME = 2 };                 // tracer.rs:20-22 (off root)
-enum { K_NEE = 0, K_BSDF = 2, K_RR = 5 };                      // tracer.rs:23-28 (off vertex)
+enum { K_NEE = 0, K_BSDF = 2, K_PHASE = 4, K_RR = 5, K_MEDIUM = 6 };  // tracer.rs:23-30 (off vertex)
 constexpr int kRrStartBounce = 3;                              // tracer.rs:46
 constexpr float kRrMinProb = 0.05f;                            // tracer.rs:47
 constexpr uint32_t kFilmTarget = 0x80000000u;
 constexpr uint32_t kPrevValid = 1u << 16, kPrevDelta = 1u << 17;
+constexpr int kMediumShift = 18;             // aux[18:32): 1-based compact id of the interior medium the ray travels in
+constexpr uint32_t kMaxMedia = (1u << 14) - 1;
 
 // Path state: struct-of-arrays of 16-byte records, so each plane is read and written with one
 // 16-byte-per-lane (1 KiB per wave) instruction — the widest, most efficient global access on CDNA4.
@@ -61,6 +63,7 @@ struct PathSoA {
   float4 *c;    // beta.z, L.xyz            L: radiance gathered so far
   uint4 *d;     // sampler pattern of the K_PATH domain | owned-pixel index |
                 // n_rec (low 16) + remaining depth (high 16) | sample-in-batch (low 16) + kPrevValid + kPrevDelta
+                // + carried-medium id (high 14)
   float4 *e;    // previous vertex position + previous bounce pdf (PrevBounce, tracer.rs:899-906); lit scenes only
   float *time;  // shutter time; scenes with motion only
 };
@@ -119,6 +122,8 @@ struct Params {
   DevScene scene;
   uint32_t sample_begin;
   const CrtMaterial *materials;
+  const DevMedium *media;          // per geom_id: the material's interior medium (present == 0: none)
+  const DevMedium *media_by_id;    // the present ones, by compact id - 1
   const CrtLight *lights;
   uint32_t n_lights;
   CrtCamera camera;
@@ -177,6 +182,24 @@ __device__ __forceinline__ uint32_t seg_append(bool want, uint32_t *lds_counter)
 __device__ __forceinline__ void add_stat(uint32_t *lds_slot, uint32_t v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   if ((threadIdx.x & 63) == 0 && v) atomicAdd(lds_slot, v);
+}
+
+// ---- interior media of the materials (openpbr.rs:225-258), derived once on the device so that the logarithms
+// are the same deterministic sequence the shading kernels use. One thread: ids are assigned in material order. ----
+__global__ void k_build_media(const CrtMaterial *materials, uint32_t n, DevMedium *media, DevMedium *by_id,
+                              uint32_t *count_out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  uint32_t count = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    DevMedium m;
+    medium_from_material(materials[i], m);
+    if (m.present) {
+      count++;
+      if (count <= kMaxMedia) { m.id = count; by_id[count - 1] = m; }
+    }
+    media[i] = m;
+  }
+  *count_out = count;
 }
 
 // ---- generate: PathSampler::new(...).new_domain(tile), camera sample, camera ray (tracer.rs:559-585) ----
@@ -307,8 +330,8 @@ __global__ __launch_bounds__(kBlock, CRT_SHADE_WAVES) void k_shade(Params P, Pat
     V3 L = splat(0.0f), beta = splat(1.0f);
     V3 n_o = splat(0.0f), n_d = splat(0.0f), sh_d = splat(0.0f), sh_c = splat(0.0f), hit_p = splat(0.0f);
     float n_ppdf = 0.0f, sh_tmax = 0.0f, time = 0.0f;
-    uint32_t meta = 0, aux = 0, pix = 0, pattern = 0;
-    bool n_delta = false;
+    uint32_t meta = 0, aux = 0, pix = 0, pattern = 0, n_med = 0;
+    bool n_delta = false, n_prev_valid = true;
     if (active) {
       const float4 A = S.a[i], B = S.b[i], Cc = S.c[i];
       const uint4 D = S.d[i];
@@ -320,6 +343,11 @@ __global__ __launch_bounds__(kBlock, CRT_SHADE_WAVES) void k_shade(Params P, Pat
       const uint32_t n_rec = meta & 0xffffu;
       const int remaining = (int)(meta >> 16);
       const bool prev_valid = (aux & kPrevValid) != 0, prev_delta = (aux & kPrevDelta) != 0;
+      const uint32_t med_id = aux >> kMediumShift;  // Ray::medium: the interior this segment travels in
+      DevMedium med;
+      med.present = 0; med.scattering = 0;
+      if (med_id) med = P.media_by_id[med_id - 1];
+      n_med = med_id;
       const uint32_t hg = H.geom[i];
       const bool has_hit = hg != kInvalid;
       const uint32_t geom = hg & 0x7fffffffu;
@@ -356,13 +384,46 @@ __global__ __launch_bounds__(kBlock, CRT_SHADE_WAVES) void k_shade(Params P, Pat
           if (has_hit) {
             const CrtMaterial &mat = P.materials[geom];
             const float cos_o = fabs_(dot(normalize(rd), rec.normal));
-            const V3 emitted = mat_emitted_directional(mat, cos_o);
-            if (len2(emitted) > 0.0f) L = L + beta * (emitted * emission_weight());
+            V3 emitted = mat_emitted_directional(mat, cos_o);
+            if (len2(emitted) > 0.0f) {
+              if (med.present) emitted = emitted * medium_transmittance(med, rec.t);  // tracer.rs:1134-1136
+              L = L + beta * (emitted * emission_weight());
+            }
           }
         }
       } else {
         s_closest++;
-        if (!has_hit) {  // tracer.rs:1321-1342: background = sky gradient (no light at infinity in scope)
+        const Sampler vdom = new_domain(Sampler{pattern, P.sample_begin + (aux & 0xffffu)}, (int)n_rec);  // :1121
+        // free-flight candidate in a scattering carried medium (tracer.rs:1159-1165)
+        float t_med = CRT_INF;
+        if (med.present && med.scattering) t_med = -(log_det(draw_rnd1(new_domain(vdom, K_MEDIUM)))) / med.sigma_bar;
+        const float t_surf = has_hit ? rec.t : CRT_INF;
+        if (t_med < t_surf) {  // === carried-medium scatter vertex (tracer.rs:1256-1319): no NEE, next emission in full ===
+          const V3 pos = ro + rd * t_med;
+          float phase_uv[4];
+          draw_sample4(new_domain(vdom, K_PHASE), phase_uv, sobol_tab);
+          const V3 dir = sample_henyey_greenstein(normalize(rd), med.g, phase_uv[0], phase_uv[1]);
+          const V3 factor = (ld3(med.sigma_s) / med.sigma_bar) * medium_chromatic(med, t_med);
+          beta = beta * (splat(1.0f) * factor);
+          bool survived = true;
+          if (n_rec >= (uint32_t)kRrStartBounce) {
+            s_rr_t++;
+            const float p_survive = rclamp(max_elem(beta), kRrMinProb, 1.0f);
+            if (p_survive < 1.0f) {
+              if (draw_rnd1(new_domain(vdom, K_RR)) >= p_survive) {
+                survived = false;
+                s_rr_k++;
+              } else {
+                beta = beta / p_survive;
+              }
+            }
+          }
+          s_vertices++;
+          if (survived) {
+            alive = true;
+            n_o = pos; n_d = dir; n_ppdf = 0.0f; n_delta = false; n_prev_valid = false;  // same medium: n_med stays
+          }
+        } else if (!has_hit) {  // tracer.rs:1321-1342: background = sky gradient (no light at infinity in scope)
           s_esc++;
           const V3 unit_direction = normalize(rd);
           const float t = 0.5f * (unit_direction.y + 1.0f);
@@ -370,7 +431,10 @@ __global__ __launch_bounds__(kBlock, CRT_SHADE_WAVES) void k_shade(Params P, Pat
           L = L + beta * background;
         } else {
           const CrtMaterial &mat = P.materials[geom];
-          const V3 atten = splat(1.0f);  // no carried medium, no volume regions
+          // tracer.rs:1352-1361: a scattering medium already paid e^{-sigma_bar t} through the free-flight
+          // competition, only the chromatic correction remains; a clear one keeps pure Beer-Lambert.
+          V3 atten = splat(1.0f);
+          if (med.present) atten = splat(1.0f) * (med.scattering ? medium_chromatic(med, rec.t) : medium_transmittance(med, rec.t));
           const float cos_o = fabs_(dot(normalize(rd), rec.normal));
           const V3 emitted = mat_emitted_directional(mat, cos_o);
           V3 emit_here = splat(0.0f);
@@ -379,7 +443,7 @@ __global__ __launch_bounds__(kBlock, CRT_SHADE_WAVES) void k_shade(Params P, Pat
           } else {
             emit_here = emitted;
           }
-          const Sampler vdom = new_domain(Sampler{pattern, P.sample_begin + (aux & 0xffffu)}, (int)n_rec);  // :1121
+          const V3 ba = beta * atten;
 
           // === 1. direct lighting by light sampling (tracer.rs:1394-1445) ===
           if (P.strategy != CRT_STRATEGY_BSDF && P.n_lights > 0) {
@@ -404,10 +468,10 @@ __global__ __launch_bounds__(kBlock, CRT_SHADE_WAVES) void k_shade(Params P, Pat
                 c = c * splat(1.0f);  // shadow_tr == ONE when unoccluded
                 nee = nee + (c * weight) / light_pdf;
               }
-              sh_c = beta * nee;  // added to L by the shadow stage iff the segment is unoccluded
+              sh_c = ba * nee;  // added to L by the shadow stage iff the segment is unoccluded
             }
           }
-          L = L + beta * emit_here;
+          L = L + ba * emit_here;
 
           // === 2. indirect lighting by BSDF sampling (tracer.rs:1459-1523) ===
           Scatter sample;
@@ -432,6 +496,8 @@ __global__ __launch_bounds__(kBlock, CRT_SHADE_WAVES) void k_shade(Params P, Pat
             if (survived) {
               alive = true;
               n_o = sample.origin; n_d = sample.dir; n_ppdf = sample.pdf; n_delta = sample.delta;
+              // materials build the ray: it carries the interior only when it refracts into the front face
+              n_med = sample.medium ? P.media[geom].id : 0u;
             }
           }
           s_vertices++;
@@ -457,7 +523,7 @@ __global__ __launch_bounds__(kBlock, CRT_SHADE_WAVES) void k_shade(Params P, Pat
       N.b[j] = make_float4(n_d.y, n_d.z, beta.x, beta.y);
       N.c[j] = make_float4(beta.z, L.x, L.y, L.z);
       N.d[j] = make_uint4(pattern, pix, ((meta & 0xffffu) + 1u) | (((meta >> 16) - 1u) << 16),
-                          sl | kPrevValid | (n_delta ? kPrevDelta : 0u));
+                          sl | (n_prev_valid ? kPrevValid : 0u) | (n_delta ? kPrevDelta : 0u) | (n_med << kMediumShift));
       if (P.n_lights) N.e[j] = make_float4(hit_p.x, hit_p.y, hit_p.z, n_ppdf);
       if (P.has_motion) N.time[j] = time;
     } else if (active) {
@@ -569,6 +635,7 @@ struct Renderer {
   float4 *staging = nullptr;
   float4 *film = nullptr;
   CrtMaterial *d_materials = nullptr;
+  DevMedium *d_media = nullptr;  // [n_materials] by geom_id, then [n_materials] by compact id
   CrtLight *d_lights = nullptr;
   uint32_t *d_pixels = nullptr;
   int grid = 2048;
@@ -585,6 +652,7 @@ struct Renderer {
     if (C) (void)hipFree(C);
     if (film) (void)hipFree(film);
     if (d_materials) (void)hipFree(d_materials);
+    if (d_media) (void)hipFree(d_media);
     if (d_lights) (void)hipFree(d_lights);
     if (d_pixels) (void)hipFree(d_pixels);
   }
@@ -748,8 +816,20 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
     ok = CRT_HIP_OK(hipMalloc(&r.d_lights, n_lights * sizeof(CrtLight))) &&
          CRT_HIP_OK(hipMemcpy(r.d_lights, lights, n_lights * sizeof(CrtLight), hipMemcpyHostToDevice));
   }
+  if (ok && n_materials) {  // interior media of the materials, derived on the device
+    uint32_t *d_count = nullptr, h_count = 0;
+    ok = CRT_HIP_OK(hipMalloc(&r.d_media, 2 * n_materials * sizeof(DevMedium))) && CRT_HIP_OK(hipMalloc(&d_count, 4));
+    if (ok) {
+      hipLaunchKernelGGL(k_build_media, dim3(1), dim3(64), 0, nullptr, r.d_materials, (uint32_t)n_materials, r.d_media,
+                         r.d_media + n_materials, d_count);
+      ok = CRT_HIP_OK(hipGetLastError()) && CRT_HIP_OK(hipMemcpy(&h_count, d_count, 4, hipMemcpyDeviceToHost));
+      ok = ok && h_count <= kMaxMedia;  // the path state carries a 14-bit medium id
+    }
+    if (d_count) (void)hipFree(d_count);
+  }
   if (!ok) { delete R; return nullptr; }
   P.materials = r.d_materials; P.lights = r.d_lights; P.pixel_index = r.d_pixels;
+  P.media = r.d_media; P.media_by_id = r.d_media ? r.d_media + n_materials : nullptr;
   hipDeviceProp_t prop;
   int dev = 0;
   (void)hipGetDevice(&dev);

@@ -15,7 +15,7 @@ namespace crt {
 namespace dev {
 
 struct HitRec { V3 p, normal; float t; bool front_face; };  // hittable.rs:10-36
-struct Scatter { V3 origin, dir, value; float pdf; bool delta; };  // material.rs:8-22
+struct Scatter { V3 origin, dir, value; float pdf; bool delta; bool medium; };  // material.rs:8-22; medium: the ray enters the interior
 
 __device__ __forceinline__ V3 ld3(const float c[3]) { return v3(c[0], c[1], c[2]); }
 
@@ -516,6 +516,7 @@ __device__ __forceinline__ V3 to_world(const Frame3 &f, V3 l) { return f.t * l.x
 __device__ bool mat_scatter(const CrtMaterial &m, V3 ray_dir, const HitRec &rec, Sampler dom, Scatter &out,
                             const uint32_t *sobol_tab) {
   if (m.kind == CRT_MAT_EMISSIVE) return false;
+  out.medium = false;
   const Frame3 frame = frame_new(rec.normal);
   const V3 v_world = -normalize(ray_dir);
   const V3 v_local = to_local(frame, v_world);
@@ -536,6 +537,7 @@ __device__ bool mat_scatter(const CrtMaterial &m, V3 ray_dir, const HitRec &rec,
       out.value = brdf * fabs_(l_local.z);
       out.pdf = pdf;
       out.delta = false;
+      out.medium = rec.front_face;  // openpbr.rs:1061-1066; the caller checks that the material has an interior at all
       return true;
     }
     V3 dir, throughput;
@@ -647,6 +649,96 @@ __device__ __forceinline__ float filter_offset(int kind, float r, float u) {
   if (kind == CRT_FILTER_BOX) return (0.5f - r) + (2.0f * r) * u;
   const float x = u < 0.5f ? r * (sqrtf(2.0f * u) - 1.0f) : r * (1.0f - sqrtf(2.0f * (1.0f - u)));
   return 0.5f + x;
+}
+
+
+// ---- carried interior medium (medium.rs:22-184, openpbr.rs:225-258) ----
+struct DevMedium {  // 48 bytes; one per material, present == 0 where the interior neither absorbs nor scatters
+  float sigma_a[3], sigma_s[3];
+  float g;
+  float sigma_bar;      // max(sigma_t_max, 1e-4): the free-flight majorant (tracer.rs:1161, :1258)
+  uint32_t present;     // interior_medium() is Some
+  uint32_t scattering;  // Medium::is_scattering (medium.rs:125-127)
+  uint32_t id;          // compact 1-based id carried by the path state (0 = no medium)
+  uint32_t pad;
+};
+__device__ __forceinline__ V3 medium_sigma_t(const DevMedium &m) { return ld3(m.sigma_a) + ld3(m.sigma_s); }
+__device__ __forceinline__ V3 medium_transmittance(const DevMedium &m, float t) {  // medium.rs:117-120
+  const V3 e = medium_sigma_t(m) * t;
+  return v3(exp_det(-e.x), exp_det(-e.y), exp_det(-e.z));
+}
+// e^{(sigma_bar - sigma_t) t}: what a scattering medium still owes after the free-flight competition
+__device__ __forceinline__ V3 medium_chromatic(const DevMedium &m, float t) {  // tracer.rs:1354-1358, :1274
+  const V3 e = (splat(m.sigma_bar) - medium_sigma_t(m)) * t;
+  return v3(exp_det(e.x), exp_det(e.y), exp_det(e.z));
+}
+__device__ __forceinline__ void medium_from_material(const CrtMaterial &m, DevMedium &out) {
+  out.present = 0; out.scattering = 0; out.id = 0; out.pad = 0; out.g = 0.0f; out.sigma_bar = 1e-4f;
+  for (int i = 0; i < 3; i++) { out.sigma_a[i] = 0.0f; out.sigma_s[i] = 0.0f; }
+  if (m.kind == CRT_MAT_EMISSIVE) return;
+  const float trans_frac = m.transmission_weight;
+  const float sss_frac = (1.0f - m.transmission_weight) * m.subsurface_weight;
+  const float total = trans_frac + sss_frac;
+  if (total <= 0.0f) return;
+  // Medium::from_transmission (medium.rs:40-66)
+  V3 ta = splat(0.0f), ts = splat(0.0f);
+  float tg = 0.0f;
+  if (!(m.transmission_depth <= 1e-6f)) {
+    const float depth = m.transmission_depth;
+    const V3 t = vclamp(ld3(m.transmission_color), splat(1e-4f), splat(1.0f));
+    const V3 extinction = v3(-log_det(t.x), -log_det(t.y), -log_det(t.z)) / depth;
+    ts = vmax(ld3(m.transmission_scatter), splat(0.0f)) / depth;
+    ta = extinction - ts;
+    const float mn = smin(smin(ta.x, ta.y), ta.z);
+    if (mn < 0.0f) ta = ta - splat(mn);
+    tg = rclamp(m.transmission_scatter_anisotropy, -0.999f, 0.999f);
+  }
+  V3 sa = ta, ss = ts;
+  float g = tg;
+  if (sss_frac > 0.0f) {  // Medium::from_subsurface (medium.rs:77-97) + Medium::blend (:103-114)
+    const V3 mfp = vmax(splat(m.subsurface_radius) * ld3(m.subsurface_radius_scale), splat(1e-3f));
+    const V3 sigma_t = splat(1.0f) / mfp;
+    const float sg = rclamp(m.subsurface_scatter_anisotropy, -0.999f, 0.999f);
+    const V3 a = vclamp(ld3(m.subsurface_color), splat(0.0f), splat(1.0f));
+    const V3 inner = (splat(9.59217f) + a * 41.6808f) + (a * 17.7126f) * a;
+    const V3 sqrt_inner = v3(sqrtf(inner.x), sqrtf(inner.y), sqrtf(inner.z));
+    const V3 s = (splat(4.09712f) + a * 4.20863f) - sqrt_inner;
+    const V3 s2 = s * s;
+    const V3 alpha_ss = vclamp((splat(1.0f) - s2) / (splat(1.0f) - s2 * sg), splat(0.0f), splat(1.0f));
+    const V3 bs = sigma_t * alpha_ss;
+    const V3 ba = sigma_t - bs;
+    const float wa = trans_frac / total, wb = sss_frac / total;
+    sa = ta * wa + ba * wb;
+    ss = ts * wa + bs * wb;
+    const float ca = (((ts.x + ts.y) + ts.z) / 3.0f) * wa;
+    const float cb = (((bs.x + bs.y) + bs.z) / 3.0f) * wb;
+    g = (ca + cb > 1e-8f) ? (tg * ca + sg * cb) / (ca + cb) : 0.0f;
+  }
+  const float sigma_t_max = max_elem(sa + ss);
+  if (sigma_t_max <= 1e-6f) return;  // openpbr.rs:253-257: inert interiors carry no medium
+  out.sigma_a[0] = sa.x; out.sigma_a[1] = sa.y; out.sigma_a[2] = sa.z;
+  out.sigma_s[0] = ss.x; out.sigma_s[1] = ss.y; out.sigma_s[2] = ss.z;
+  out.g = g;
+  out.sigma_bar = rmax(sigma_t_max, 1e-4f);
+  out.present = 1;
+  out.scattering = max_elem(ss) > 1e-6f ? 1u : 0u;
+}
+__device__ __forceinline__ V3 sample_henyey_greenstein(V3 wi, float g, float u1, float u2) {  // medium.rs:158-184
+  float cos_theta;
+  if (fabs_(g) < 1e-3f) cos_theta = 1.0f - 2.0f * u1;
+  else {
+    const float sq = (1.0f - g * g) / (1.0f - g + 2.0f * g * u1);
+    cos_theta = (1.0f + g * g - sq * sq) / (2.0f * g);
+  }
+  cos_theta = rclamp(cos_theta, -1.0f, 1.0f);
+  const float sin_theta = sqrtf(rmax(1.0f - cos_theta * cos_theta, 0.0f));
+  const float phi = 2.0f * CRT_PI * u2;
+  const V3 up = fabs_(wi.z) < 0.999f ? v3(0.0f, 0.0f, 1.0f) : v3(1.0f, 0.0f, 0.0f);
+  const V3 t = normalize(cross(wi, up));
+  const V3 b = cross(wi, t);
+  float sp, cp;
+  sincos_det(phi, sp, cp);
+  return normalize((t * (sin_theta * cp) + b * (sin_theta * sp)) + wi * cos_theta);
 }
 
 }  // namespace dev

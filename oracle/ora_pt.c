@@ -74,7 +74,7 @@ static v3 sky(v3 unit_direction) { /* tracer.rs:1334-1336 */
 
 #define ORA_MAX_RECORDS 4096
 
-/* tracer.rs:1086-1558, surface arm (no carried medium, no volume regions, no guiding). */
+/* tracer.rs:1086-1558: surface arm + carried interior medium (no volume regions, no guiding). */
 static v3 trace_path(const OraRenderJob *job, const OraRay *r, OraSampler sampler, VertexRec *records,
                      OraRayStats *stats) {
   const int forward = job->forward;
@@ -87,6 +87,8 @@ static v3 trace_path(const OraRenderJob *job, const OraRay *r, OraSampler sample
   v3 terminal = v3_splat(0.0f);
   v3 L = v3_splat(0.0f); /* forward mode only */
   const v3 one = v3_splat(1.0f);
+  OraMedium med; int has_med = 0; /* Ray::medium (ray.rs): the interior the current ray travels in */
+  memset(&med, 0, sizeof med);
 
   for (;;) {
     OraSampler v = ora_new_domain(path, (int)n_rec);
@@ -99,6 +101,7 @@ static v3 trace_path(const OraRenderJob *job, const OraRay *r, OraSampler sample
           float cos_o = ora_abs(v3_dot(v3_normalize(ray.dir), hit.rec.normal));
           v3 emitted = ora_mat_emitted_directional(hit.mat, cos_o);
           if (v3_len2(emitted) > 0.0f) {
+            if (has_med) emitted = v3_mul(emitted, ora_medium_transmittance(&med, hit.rec.t)); /* tracer.rs:1134-1136 */
             float w = bounce_emission_weight(job, &prev, &hit);
             if (forward) L = v3_add(L, v3_mul(beta, v3_scale(emitted, w)));
             else { records[n_rec - 1].next_emit = emitted; records[n_rec - 1].next_emit_weight = w; }
@@ -111,6 +114,49 @@ static v3 trace_path(const OraRenderJob *job, const OraRay *r, OraSampler sample
     stats->closest_hit++;
     WorldHit hit;
     int has_hit = world_intersect(job, &ray, 0.001f, ORA_INF, &hit); /* tracer.rs:1152 */
+    const float t_surf = has_hit ? hit.rec.t : ORA_INF;
+    /* free-flight candidate in a scattering carried medium (tracer.rs:1159-1165) */
+    float t_med = ORA_INF;
+    if (has_med && ora_medium_is_scattering(&med)) {
+      float sigma_t_max = ora_max(ora_medium_sigma_t_max(&med), 1e-4f);
+      t_med = -(ora_logf(ora_draw_rnd1(ora_new_domain(v, K_MEDIUM)))) / sigma_t_max;
+    }
+    if (t_med < t_surf) { /* === carried-medium scatter vertex (tracer.rs:1256-1319) === */
+      float sigma_bar = ora_max(ora_medium_sigma_t_max(&med), 1e-4f);
+      v3 pos = v3_add(ray.origin, v3_scale(ray.dir, t_med));
+      float phase_uv[4];
+      ora_draw_sample4(ora_new_domain(v, K_PHASE), phase_uv);
+      v3 dir = ora_sample_henyey_greenstein(v3_normalize(ray.dir), med.g, phase_uv[0], phase_uv[1]);
+      v3 e = v3_scale(v3_sub(v3_splat(sigma_bar), v3_add(med.sigma_a, med.sigma_s)), t_med);
+      v3 factor = v3_mul(v3_divs(med.sigma_s, sigma_bar), v3_new(ora_expf(e.x), ora_expf(e.y), ora_expf(e.z)));
+      VertexRec vrec;
+      vrec.atten = one; vrec.segment_emit = v3_splat(0.0f); vrec.emit_here = v3_splat(0.0f); vrec.nee = v3_splat(0.0f);
+      vrec.factor = factor; vrec.next_emit = v3_splat(0.0f); vrec.next_emit_weight = 1.0f;
+      beta = v3_mul(beta, v3_mul(one, factor));
+      int survived = 1;
+      if (n_rec >= RR_START_BOUNCE) {
+        stats->rr_tested++;
+        float p_survive = ora_clamp(v3_max_elem(beta), RR_MIN_PROB, 1.0f);
+        if (p_survive < 1.0f) {
+          if (ora_draw_rnd1(ora_new_domain(v, K_RR)) >= p_survive) {
+            survived = 0;
+            stats->rr_killed++;
+            vrec.factor = v3_splat(0.0f);
+          } else {
+            vrec.factor = v3_divs(vrec.factor, p_survive);
+            beta = v3_divs(beta, p_survive);
+          }
+        }
+      }
+      stats->vertices++;
+      if (n_rec >= ORA_MAX_RECORDS) abort();
+      records[n_rec++] = vrec;
+      if (!survived) break;
+      ray.origin = pos; ray.dir = dir; ray.mask = ORA_MASK_INDIRECT; /* same medium, time kept */
+      remaining -= 1;
+      prev.valid = 0;
+      continue;
+    }
     if (!has_hit) { /* tracer.rs:1321-1342 */
       stats->ended_escaped++;
       v3 unit_direction = v3_normalize(ray.dir);
@@ -122,7 +168,18 @@ static v3 trace_path(const OraRenderJob *job, const OraRay *r, OraSampler sample
     }
     const OraHitRecord rec = hit.rec;
     const OraMaterial *mat = hit.mat;
-    const v3 atten = one; /* tracer.rs:1352-1361 with no medium, no volumes */
+    /* tracer.rs:1352-1361: a scattering medium already paid e^{-sigma_bar t} through the free-flight
+     * competition, so only the chromatic correction remains; a clear one keeps pure Beer-Lambert. */
+    v3 atten = one;
+    if (has_med) {
+      if (ora_medium_is_scattering(&med)) {
+        float sigma_bar = ora_max(ora_medium_sigma_t_max(&med), 1e-4f);
+        v3 e = v3_scale(v3_sub(v3_splat(sigma_bar), v3_add(med.sigma_a, med.sigma_s)), rec.t);
+        atten = v3_mul(one, v3_new(ora_expf(e.x), ora_expf(e.y), ora_expf(e.z)));
+      } else {
+        atten = v3_mul(one, ora_medium_transmittance(&med, rec.t));
+      }
+    }
 
     /* tracer.rs:1369-1381 */
     float cos_o = ora_abs(v3_dot(v3_normalize(ray.dir), rec.normal));
@@ -171,8 +228,9 @@ static v3 trace_path(const OraRenderJob *job, const OraRay *r, OraSampler sample
     vrec.atten = atten; vrec.segment_emit = v3_splat(0.0f); vrec.emit_here = emit_here; vrec.nee = nee;
     vrec.factor = v3_splat(0.0f); vrec.next_emit = v3_splat(0.0f); vrec.next_emit_weight = 1.0f;
     if (forward) { /* two separate adds: the second is what a deferred shadow test contributes */
-      L = v3_add(L, v3_mul(beta, emit_here));
-      L = v3_add(L, v3_mul(beta, nee));
+      const v3 ba = v3_mul(beta, atten);
+      L = v3_add(L, v3_mul(ba, emit_here));
+      L = v3_add(L, v3_mul(ba, nee));
     }
 
     /* === 2. bounce (tracer.rs:1459-1523) === */
@@ -204,6 +262,7 @@ static v3 trace_path(const OraRenderJob *job, const OraRay *r, OraSampler sample
         if (n_rec >= ORA_MAX_RECORDS) abort();
         records[n_rec++] = vrec;
         ray.origin = sample.origin; ray.dir = sample.dir; ray.mask = ORA_MASK_INDIRECT; /* time kept */
+        has_med = sample.medium ? ora_interior_medium(mat, &med) : 0; /* materials build the ray: openpbr.rs:1061-1066 */
         remaining -= 1;
         continue;
       }

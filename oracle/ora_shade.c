@@ -559,6 +559,7 @@ static v3 frame_to_world(const Frame *f, v3 l) {
 
 int ora_mat_scatter(const OraMaterial *m, v3 ray_dir, const OraHitRecord *rec, OraSampler dom, OraScatter *out) {
   if (m->kind == ORA_MAT_EMISSIVE) return 0; /* emissive.rs:30-38 */
+  out->medium = 0;
   /* openpbr.rs:1026-1136 scatter_resolved */
   Frame frame = frame_new(rec->normal);
   v3 v_world = v3_neg(v3_normalize(ray_dir));
@@ -580,6 +581,8 @@ int ora_mat_scatter(const OraMaterial *m, v3 ray_dir, const OraHitRecord *rec, O
       out->value = v3_scale(brdf, ora_abs(l_local.z));
       out->pdf = pdf;
       out->delta = 0;
+      OraMedium med; /* openpbr.rs:1061-1066: only a ray refracting INTO the front face carries the interior */
+      out->medium = (rec->front_face && ora_interior_medium(m, &med)) ? 1 : 0;
       return 1;
     }
     v3 dir, throughput;
@@ -636,6 +639,100 @@ v3 ora_mat_emitted_directional(const OraMaterial *m, float cos_theta_o) {
   if (m->coat_weight <= 0.0f) return uncoated;
   v3 dark = coat_darkening_factor(c3(m->base_color), m->coat_ior, m->coat_darkening);
   return v3_mul(v3_mul(uncoated, ora_coat_passage(m, cos_theta_o)), dark);
+}
+
+/* ------------------------------------------------------------------ */
+/* medium.rs — carried interior medium                                 */
+/* ------------------------------------------------------------------ */
+OraMedium ora_medium_from_transmission(v3 tint, float depth, v3 scatter, float anisotropy) { /* medium.rs:40-66 */
+  OraMedium m;
+  if (depth <= 1e-6f) { m.sigma_a = v3_splat(0.0f); m.sigma_s = v3_splat(0.0f); m.g = 0.0f; return m; }
+  v3 t = v3_clamp(tint, v3_splat(1e-4f), v3_splat(1.0f));
+  v3 extinction = v3_divs(v3_new(-ora_logf(t.x), -ora_logf(t.y), -ora_logf(t.z)), depth);
+  v3 sigma_s = v3_divs(v3_max(scatter, v3_splat(0.0f)), depth);
+  v3 sigma_a = v3_sub(extinction, sigma_s);
+  float mn = v3_min_elem(sigma_a);
+  if (mn < 0.0f) sigma_a = v3_sub(sigma_a, v3_splat(mn));
+  m.sigma_a = sigma_a; m.sigma_s = sigma_s; m.g = ora_clamp(anisotropy, -0.999f, 0.999f);
+  return m;
+}
+OraMedium ora_medium_from_subsurface(v3 albedo, float radius, v3 radius_scale, float g) { /* medium.rs:77-97 */
+  v3 mfp = v3_max(v3_mul(v3_splat(radius), radius_scale), v3_splat(1e-3f));
+  v3 sigma_t = v3_div(v3_splat(1.0f), mfp);
+  g = ora_clamp(g, -0.999f, 0.999f);
+  v3 a = v3_clamp(albedo, v3_splat(0.0f), v3_splat(1.0f));
+  /* inner = 9.59217 + 41.6808*a + 17.7126*a*a, left to right as glam evaluates it */
+  v3 inner = v3_add(v3_add(v3_splat(9.59217f), v3_scale(a, 41.6808f)), v3_mul(v3_scale(a, 17.7126f), a));
+  v3 sqrt_inner = v3_new(sqrtf(inner.x), sqrtf(inner.y), sqrtf(inner.z));
+  v3 s = v3_sub(v3_add(v3_splat(4.09712f), v3_scale(a, 4.20863f)), sqrt_inner);
+  v3 s2 = v3_mul(s, s);
+  v3 alpha_ss = v3_clamp(v3_div(v3_sub(v3_splat(1.0f), s2), v3_sub(v3_splat(1.0f), v3_scale(s2, g))), v3_splat(0.0f),
+                         v3_splat(1.0f));
+  OraMedium m;
+  m.sigma_s = v3_mul(sigma_t, alpha_ss);
+  m.sigma_a = v3_sub(sigma_t, m.sigma_s);
+  m.g = g;
+  return m;
+}
+OraMedium ora_medium_blend(const OraMedium *a, float wa, const OraMedium *b, float wb) { /* medium.rs:103-114 */
+  OraMedium m;
+  m.sigma_a = v3_add(v3_scale(a->sigma_a, wa), v3_scale(b->sigma_a, wb));
+  m.sigma_s = v3_add(v3_scale(a->sigma_s, wa), v3_scale(b->sigma_s, wb));
+  float sa = (((a->sigma_s.x + a->sigma_s.y) + a->sigma_s.z) / 3.0f) * wa;
+  float sb = (((b->sigma_s.x + b->sigma_s.y) + b->sigma_s.z) / 3.0f) * wb;
+  m.g = (sa + sb > 1e-8f) ? (a->g * sa + b->g * sb) / (sa + sb) : 0.0f;
+  return m;
+}
+v3 ora_medium_transmittance(const OraMedium *m, float t) { /* medium.rs:117-120 */
+  v3 e = v3_scale(v3_add(m->sigma_a, m->sigma_s), t);
+  return v3_new(ora_expf(-e.x), ora_expf(-e.y), ora_expf(-e.z));
+}
+int ora_medium_is_scattering(const OraMedium *m) { return v3_max_elem(m->sigma_s) > 1e-6f; }
+float ora_medium_sigma_t_max(const OraMedium *m) { return v3_max_elem(v3_add(m->sigma_a, m->sigma_s)); }
+v3 ora_medium_albedo(const OraMedium *m) {
+  v3 denom = v3_max(v3_add(m->sigma_a, m->sigma_s), v3_splat(1e-6f));
+  return v3_div(m->sigma_s, denom);
+}
+int ora_interior_medium(const OraMaterial *m, OraMedium *out) { /* openpbr.rs:225-258 */
+  if (m->kind == ORA_MAT_EMISSIVE) return 0;
+  float trans_frac = m->transmission_weight;
+  float sss_frac = (1.0f - m->transmission_weight) * m->subsurface_weight;
+  float total = trans_frac + sss_frac;
+  if (total <= 0.0f) return 0;
+  OraMedium trans_volume = ora_medium_from_transmission(c3(m->transmission_color), m->transmission_depth,
+                                                        c3(m->transmission_scatter), m->transmission_scatter_anisotropy);
+  OraMedium medium;
+  if (sss_frac > 0.0f) {
+    OraMedium sss_volume = ora_medium_from_subsurface(c3(m->subsurface_color), m->subsurface_radius,
+                                                      c3(m->subsurface_radius_scale), m->subsurface_scatter_anisotropy);
+    medium = ora_medium_blend(&trans_volume, trans_frac / total, &sss_volume, sss_frac / total);
+  } else {
+    medium = trans_volume;
+  }
+  if (ora_medium_sigma_t_max(&medium) <= 1e-6f) return 0;
+  *out = medium;
+  return 1;
+}
+float ora_hg_phase(float cos_theta, float g) { /* medium.rs:148-152 */
+  float denom = ora_max(1.0f + g * g - 2.0f * g * cos_theta, 1e-6f);
+  return (1.0f - g * g) / (4.0f * ORA_PI * denom * sqrtf(denom));
+}
+v3 ora_sample_henyey_greenstein(v3 wi, float g, float u1, float u2) { /* medium.rs:158-184 */
+  float cos_theta;
+  if (ora_abs(g) < 1e-3f) cos_theta = 1.0f - 2.0f * u1;
+  else {
+    float sq = (1.0f - g * g) / (1.0f - g + 2.0f * g * u1);
+    cos_theta = (1.0f + g * g - sq * sq) / (2.0f * g);
+  }
+  cos_theta = ora_clamp(cos_theta, -1.0f, 1.0f);
+  float sin_theta = sqrtf(ora_max(1.0f - cos_theta * cos_theta, 0.0f));
+  float phi = 2.0f * ORA_PI * u2;
+  v3 up = ora_abs(wi.z) < 0.999f ? v3_new(0.0f, 0.0f, 1.0f) : v3_new(1.0f, 0.0f, 0.0f);
+  v3 t = v3_normalize(v3_cross(wi, up));
+  v3 b = v3_cross(wi, t);
+  float sp, cp;
+  ora_sincosf(phi, &sp, &cp);
+  return v3_normalize(v3_add(v3_add(v3_scale(t, sin_theta * cp), v3_scale(b, sin_theta * sp)), v3_scale(wi, cos_theta)));
 }
 
 /* ------------------------------------------------------------------ */

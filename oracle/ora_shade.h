@@ -39,12 +39,25 @@ void ora_material_emissive(OraMaterial *m, float r, float g, float b);
 typedef struct { v3 p, normal; float t; int front_face; } OraHitRecord;
 
 /* material.rs:8-22 ScatterSample; the continuation ray's origin/direction. */
-typedef struct { v3 origin, dir; v3 value; float pdf; int delta; } OraScatter;
+typedef struct { v3 origin, dir; v3 value; float pdf; int delta; int medium; /* ray enters the interior medium */ } OraScatter;
 
 int ora_mat_scatter(const OraMaterial *m, v3 ray_dir, const OraHitRecord *rec, OraSampler bsdf_dom, OraScatter *out); /* openpbr.rs:1026-1136 */
 int ora_mat_eval(const OraMaterial *m, v3 ray_dir, const OraHitRecord *rec, v3 wi, v3 *value, float *pdf);          /* openpbr.rs:1138-1158 */
 v3 ora_mat_emitted(const OraMaterial *m);                                                                        /* openpbr.rs:1202-1204 */
 v3 ora_mat_emitted_directional(const OraMaterial *m, float cos_theta_o);                                        /* openpbr.rs:1211-1218 */
+
+/* medium.rs:22-160: homogeneous interior medium carried by a ray that refracted into a closed surface. */
+typedef struct { v3 sigma_a, sigma_s; float g; } OraMedium;
+OraMedium ora_medium_from_transmission(v3 tint, float depth, v3 scatter, float anisotropy);  /* medium.rs:40-66 */
+OraMedium ora_medium_from_subsurface(v3 albedo, float radius, v3 radius_scale, float g);      /* medium.rs:77-97 */
+OraMedium ora_medium_blend(const OraMedium *a, float wa, const OraMedium *b, float wb);       /* medium.rs:103-114 */
+v3 ora_medium_transmittance(const OraMedium *m, float t);                                     /* medium.rs:117-120 */
+int ora_medium_is_scattering(const OraMedium *m);                                             /* medium.rs:125-127 */
+float ora_medium_sigma_t_max(const OraMedium *m);                                             /* medium.rs:131-133 */
+v3 ora_medium_albedo(const OraMedium *m);                                                     /* medium.rs:136-140 */
+int ora_interior_medium(const OraMaterial *m, OraMedium *out);                                /* openpbr.rs:225-258; 0 = None */
+float ora_hg_phase(float cos_theta, float g);                                                 /* medium.rs:148-152 */
+v3 ora_sample_henyey_greenstein(v3 wi, float g, float u1, float u2);                          /* medium.rs:158-184 */
 
 /* Local-frame entry points for known-answer tests. */
 v3 ora_eval_all(const OraMaterial *m, v3 v_local, v3 l_local, int entering);  /* openpbr.rs:629-683 */

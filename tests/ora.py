@@ -109,7 +109,12 @@ class Sampler(C.Structure):
 
 
 class Scatter(C.Structure):
-    _fields_ = [("origin", V3), ("dir", V3), ("value", V3), ("pdf", C.c_float), ("delta", C.c_int)]
+    _fields_ = [("origin", V3), ("dir", V3), ("value", V3), ("pdf", C.c_float), ("delta", C.c_int),
+                ("medium", C.c_int)]
+
+
+class Medium(C.Structure):
+    _fields_ = [("sigma_a", V3), ("sigma_s", V3), ("g", C.c_float)]
 
 
 LIGHT_SPHERE, LIGHT_RECT = 0, 1
@@ -250,6 +255,15 @@ def lib():
     L.ora_concentric_disk.restype = V3
     L.ora_concentric_disk.argtypes = [C.c_float, C.c_float]
     for n, res, args in [
+        ("ora_medium_from_transmission", Medium, [V3, C.c_float, V3, C.c_float]),
+        ("ora_medium_from_subsurface", Medium, [V3, C.c_float, V3, C.c_float]),
+        ("ora_medium_transmittance", V3, [C.POINTER(Medium), C.c_float]),
+        ("ora_medium_is_scattering", C.c_int, [C.POINTER(Medium)]),
+        ("ora_medium_sigma_t_max", C.c_float, [C.POINTER(Medium)]),
+        ("ora_medium_albedo", V3, [C.POINTER(Medium)]),
+        ("ora_interior_medium", C.c_int, [MP, C.POINTER(Medium)]),
+        ("ora_hg_phase", C.c_float, [C.c_float, C.c_float]),
+        ("ora_sample_henyey_greenstein", V3, [V3, C.c_float, C.c_float, C.c_float]),
         ("ora_t_sheen_charlie", C.c_float, [C.c_float] * 4),
         ("ora_t_coat_darkening_factor", V3, [V3, C.c_float, C.c_float]),
         ("ora_t_coat_attenuation", V3, [MP, C.c_float, C.c_float]),

@@ -366,6 +366,98 @@ def test_subsurface_shifts_diffuse_color():  # openpbr.rs:2134-2171
     assert a[1] < b[1] and a[2] < b[2]
 
 
+# ---- carried interior medium: openpbr.rs:1985-2131, medium.rs:186-245 ----
+def _interior(m):
+    """sample_interior_medium (openpbr.rs:1985-2000): the medium of the first sample that refracts into the surface."""
+    rec = rec_z()
+    for i in range(1, 257):
+        s = scatter(m, R_IN, rec, i)
+        if s is not None and s.dir.z < 0:
+            med = ora.Medium()
+            has = L.ora_interior_medium(C.byref(m), C.byref(med))
+            assert bool(s.medium) == bool(has)
+            return med if s.medium else None
+    raise AssertionError("material never transmitted")
+
+
+def test_transmission_scatter_wires_into_interior_medium():  # openpbr.rs:2003-2030
+    m = glass(specular_roughness=0.25, transmission_color=(0.5, 0.7, 0.9), transmission_depth=2.0,
+              transmission_scatter=(0.2, 0.2, 0.1), transmission_scatter_anisotropy=0.5)
+    med = _interior(m)
+    assert med is not None and L.ora_medium_is_scattering(C.byref(med))
+    assert np.abs(med.sigma_s.np() - np.array([0.1, 0.1, 0.05])).max() < 1e-5
+    ext = med.sigma_a.np() + med.sigma_s.np()
+    assert np.abs(ext - (-np.log(np.array([0.5, 0.7, 0.9])) / 2.0)).max() < 1e-5
+    assert med.g == 0.5
+
+
+def test_transmission_scatter_negative_absorption_shifts_to_gray():  # openpbr.rs:2034-2043
+    m = L.ora_medium_from_transmission(ora.v3((1, 1, 1)), 1.0, ora.v3((0.1, 0.2, 0.4)), 0.0)
+    a = m.sigma_a.np()
+    assert a.min() >= 0.0 and abs(a[2]) < 1e-6 and a[0] > a[1] > a[2]
+
+
+def test_van_de_hulst_inversion_boosts_single_scatter_albedo():  # openpbr.rs:2046-2066
+    one = ora.v3((1, 1, 1))
+    m = L.ora_medium_from_subsurface(ora.v3((0.5,) * 3), 1.0, one, 0.0)
+    a = L.ora_medium_albedo(C.byref(m)).x
+    assert abs(a - 0.9117) < 5e-3
+    hi = L.ora_medium_from_subsurface(ora.v3((0.95,) * 3), 1.0, one, 0.0)
+    lo = L.ora_medium_from_subsurface(ora.v3((0.05,) * 3), 1.0, one, 0.0)
+    assert L.ora_medium_albedo(C.byref(hi)).x > 0.99
+    assert L.ora_medium_albedo(C.byref(lo)).x < a < L.ora_medium_albedo(C.byref(hi)).x
+    fwd = L.ora_medium_from_subsurface(ora.v3((0.5,) * 3), 1.0, one, 0.9)
+    assert L.ora_medium_albedo(C.byref(fwd)).x > a
+    assert abs((m.sigma_a.x + m.sigma_s.x) - 1.0) < 1e-5
+
+
+def test_interior_medium_blends_subsurface_into_glass():  # openpbr.rs:2069-2098
+    m = glass(specular_roughness=0.25, transmission_depth=1.0, subsurface_weight=1.0, subsurface_color=(0.5, 0.5, 0.5),
+              subsurface_radius=0.1, subsurface_radius_scale=(1.0, 1.0, 1.0), subsurface_scatter_anisotropy=0.3,
+              transmission_weight=0.5)
+    med = _interior(m)
+    assert med is not None and L.ora_medium_is_scattering(C.byref(med))
+    assert abs(med.g - 0.3) < 1e-5
+    full = L.ora_medium_from_subsurface(ora.v3((0.5,) * 3), 0.1, ora.v3((1, 1, 1)), 0.3)
+    assert np.abs(med.sigma_s.np() - full.sigma_s.np() * 0.5).max() < 1e-3
+
+
+def test_inert_glass_attaches_no_medium():  # openpbr.rs:2102-2113
+    assert _interior(glass(specular_roughness=0.25)) is None
+
+
+def test_medium_transmittance():  # openpbr.rs:2116-2131
+    m0 = L.ora_medium_from_transmission(ora.v3((0.5, 0.5, 0.5)), 0.0, ora.v3((0, 0, 0)), 0.0)
+    assert np.linalg.norm(L.ora_medium_transmittance(C.byref(m0), 1.0).np() - 1.0) < 1e-4
+    m = L.ora_medium_from_transmission(ora.v3((0.5, 0.7, 0.9)), 1.0, ora.v3((0, 0, 0)), 0.0)
+    short, long_ = L.ora_medium_transmittance(C.byref(m), 0.1).np(), L.ora_medium_transmittance(C.byref(m), 2.0).np()
+    assert (long_ < short).all()
+    # at the authored depth the transmittance is the authored colour (medium.rs:8-11)
+    assert np.abs(L.ora_medium_transmittance(C.byref(m), 1.0).np() - np.array([0.5, 0.7, 0.9])).max() < 1e-5
+
+
+def test_hg_phase_normalizes_over_sphere():  # medium.rs:190-206
+    for g in (-0.7, 0.0, 0.4, 0.9):
+        n = 20000
+        mu = -1.0 + 2.0 * (np.arange(n) + 0.5) / n
+        total = sum(L.ora_hg_phase(float(x), g) for x in mu)
+        assert abs(2.0 * math.pi * total * (2.0 / n) - 1.0) < 1e-3, g
+
+
+def test_hg_sampling_matches_the_phase_convention():  # medium.rs:208-245: g > 0 scatters forward, isotropic at g = 0
+    wi = ora.v3((0, 0, 1))
+    s = np.zeros(3)
+    for i in range(2048):  # openpbr.rs:2174-2188
+        s += L.ora_sample_henyey_greenstein(wi, 0.0, ((i * 13 + 7) % 1024) / 1024.0, ((i * 31 + 5) % 1024) / 1024.0).np()
+    assert np.linalg.norm(s / 2048.0) < 0.05
+    for g in (0.6, -0.6):
+        mean = np.mean([L.ora_sample_henyey_greenstein(wi, g, (i + 0.5) / 512.0, ((i * 31 + 5) % 512) / 512.0).z
+                        for i in range(512)])
+        assert abs(mean - g) < 0.02  # E[cos theta] = g for Henyey-Greenstein
+        d = L.ora_sample_henyey_greenstein(ora.v3(norm((0.3, -0.5, 0.8))), g, 0.37, 0.81).np()
+        assert abs(np.linalg.norm(d) - 1.0) < 1e-5
+
+
 def test_thin_walled_transmission_scatters_downward():  # openpbr.rs:2191-2216
     m = openpbr(transmission_weight=1.0, transmission_color=(0.7, 0.9, 0.7), thin_walled=1)
     rec = rec_z(normal=(0, 1, 0))
