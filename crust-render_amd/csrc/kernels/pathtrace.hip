@@ -303,6 +303,9 @@ __global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_extend(Params P, P
 }
 
 // ---- shade: one iteration of trace_path's loop body for every live path (tracer.rs:1118-1530) ----
+// MEDIA: some material of the scene has an interior medium; scenes without one run the leaner instance (the medium
+// code costs k_shade 80 spilled VGPRs at three waves per SIMD).
+template <bool MEDIA>
 __global__ __launch_bounds__(kBlock, CRT_SHADE_WAVES) void k_shade(Params P, PathSoA S, PathSoA N, HitSoA H, ShadowSoA Q, Counters *C,
                                                   int cur, float4 *staging) {
   __shared__ uint32_t sobol_tab[kSobolLdsWords];
@@ -343,10 +346,10 @@ __global__ __launch_bounds__(kBlock, CRT_SHADE_WAVES) void k_shade(Params P, Pat
       const uint32_t n_rec = meta & 0xffffu;
       const int remaining = (int)(meta >> 16);
       const bool prev_valid = (aux & kPrevValid) != 0, prev_delta = (aux & kPrevDelta) != 0;
-      const uint32_t med_id = aux >> kMediumShift;  // Ray::medium: the interior this segment travels in
+      const uint32_t med_id = MEDIA ? aux >> kMediumShift : 0u;  // Ray::medium: the interior this segment travels in
       DevMedium med;
       med.present = 0; med.scattering = 0;
-      if (med_id) med = P.media_by_id[med_id - 1];
+      if (MEDIA && med_id) med = P.media_by_id[med_id - 1];
       n_med = med_id;
       const uint32_t hg = H.geom[i];
       const bool has_hit = hg != kInvalid;
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(kBlock, CRT_SHADE_WAVES) void k_shade(Params P, Pat
             const float cos_o = fabs_(dot(normalize(rd), rec.normal));
             V3 emitted = mat_emitted_directional(mat, cos_o);
             if (len2(emitted) > 0.0f) {
-              if (med.present) emitted = emitted * medium_transmittance(med, rec.t);  // tracer.rs:1134-1136
+              if (MEDIA && med.present) emitted = emitted * medium_transmittance(med, rec.t);  // tracer.rs:1134-1136
               L = L + beta * (emitted * emission_weight());
             }
           }
@@ -396,9 +399,9 @@ __global__ __launch_bounds__(kBlock, CRT_SHADE_WAVES) void k_shade(Params P, Pat
         const Sampler vdom = new_domain(Sampler{pattern, P.sample_begin + (aux & 0xffffu)}, (int)n_rec);  // :1121
         // free-flight candidate in a scattering carried medium (tracer.rs:1159-1165)
         float t_med = CRT_INF;
-        if (med.present && med.scattering) t_med = -(log_det(draw_rnd1(new_domain(vdom, K_MEDIUM)))) / med.sigma_bar;
+        if (MEDIA && med.present && med.scattering) t_med = -(log_det(draw_rnd1(new_domain(vdom, K_MEDIUM)))) / med.sigma_bar;
         const float t_surf = has_hit ? rec.t : CRT_INF;
-        if (t_med < t_surf) {  // === carried-medium scatter vertex (tracer.rs:1256-1319): no NEE, next emission in full ===
+        if (MEDIA && t_med < t_surf) {  // === carried-medium scatter vertex (tracer.rs:1256-1319): no NEE, next emission in full ===
           const V3 pos = ro + rd * t_med;
           float phase_uv[4];
           draw_sample4(new_domain(vdom, K_PHASE), phase_uv, sobol_tab);
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(kBlock, CRT_SHADE_WAVES) void k_shade(Params P, Pat
           // tracer.rs:1352-1361: a scattering medium already paid e^{-sigma_bar t} through the free-flight
           // competition, only the chromatic correction remains; a clear one keeps pure Beer-Lambert.
           V3 atten = splat(1.0f);
-          if (med.present) atten = splat(1.0f) * (med.scattering ? medium_chromatic(med, rec.t) : medium_transmittance(med, rec.t));
+          if (MEDIA && med.present) atten = splat(1.0f) * (med.scattering ? medium_chromatic(med, rec.t) : medium_transmittance(med, rec.t));
           const float cos_o = fabs_(dot(normalize(rd), rec.normal));
           const V3 emitted = mat_emitted_directional(mat, cos_o);
           V3 emit_here = splat(0.0f);
@@ -497,7 +500,7 @@ __global__ __launch_bounds__(kBlock, CRT_SHADE_WAVES) void k_shade(Params P, Pat
               alive = true;
               n_o = sample.origin; n_d = sample.dir; n_ppdf = sample.pdf; n_delta = sample.delta;
               // materials build the ray: it carries the interior only when it refracts into the front face
-              n_med = sample.medium ? P.media[geom].id : 0u;
+              n_med = (MEDIA && sample.medium) ? P.media[geom].id : 0u;
             }
           }
           s_vertices++;
@@ -636,6 +639,7 @@ struct Renderer {
   float4 *film = nullptr;
   CrtMaterial *d_materials = nullptr;
   DevMedium *d_media = nullptr;  // [n_materials] by geom_id, then [n_materials] by compact id
+  bool has_media = false;
   CrtLight *d_lights = nullptr;
   uint32_t *d_pixels = nullptr;
   int grid = 2048;
@@ -728,7 +732,8 @@ struct Renderer {
     for (uint32_t it = 0; it <= P.max_depth; it++) {
       if (d_tstats) timed(0, st, [&] { hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kBlock), 0, st, p, S[cur], H, C, cur, it == 0 ? 1 : 0, d_tstats); });
       else timed(0, st, [&] { hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kBlock), 0, st, p, S[cur], H, C, cur, it == 0 ? 1 : 0, d_tstats); });
-      timed(1, st, [&] { hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, st, p, S[cur], S[1 - cur], H, Q, C, cur, staging); });
+      if (has_media) timed(1, st, [&] { hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(kBlock), 0, st, p, S[cur], S[1 - cur], H, Q, C, cur, staging); });
+      else timed(1, st, [&] { hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(kBlock), 0, st, p, S[cur], S[1 - cur], H, Q, C, cur, staging); });
       if (P.n_lights > 0 && P.strategy != CRT_STRATEGY_BSDF) {
         if (d_tstats) timed(2, st, [&] { hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(kBlock), 0, st, p, S[1 - cur], Q, C, staging, d_tstats + 1); });
         else timed(2, st, [&] { hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(kBlock), 0, st, p, S[1 - cur], Q, C, staging, d_tstats); });
@@ -824,6 +829,7 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
                          r.d_media + n_materials, d_count);
       ok = CRT_HIP_OK(hipGetLastError()) && CRT_HIP_OK(hipMemcpy(&h_count, d_count, 4, hipMemcpyDeviceToHost));
       ok = ok && h_count <= kMaxMedia;  // the path state carries a 14-bit medium id
+      r.has_media = h_count > 0;
     }
     if (d_count) (void)hipFree(d_count);
   }
