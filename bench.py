@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=128, help="spp of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = this box's share: min(affinity, 16 per GPU))")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1; gloo (CPU tensors, ranks may share a GPU) rehearses the N > 1 path on a 1-GPU box")
     args = ap.parse_args()
 
     import numpy as np
@@ -61,12 +63,20 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 through torch.distributed.run (one process per GPU)")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
+    n_dev = max(torch.cuda.device_count(), 1)
+    if args.backend == "nccl" and local_rank >= n_dev:
+        raise SystemExit("rank %d has no GPU of its own (%d visible): RCCL needs one GPU per rank" % (local_rank, n_dev))
+    dev_index = local_rank % n_dev
+    torch.cuda.set_device(dev_index)
+    coll = "cuda" if args.backend == "nccl" else "cpu"  # where collective operands live
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist_mod.init_process_group(backend="gloo")
         dist = dist_mod
 
     crt = load_package()
@@ -97,15 +107,15 @@ def main():
         r.render_samples(k * spp_step, spp_step, stream)
     r.film_to(d_rgb, stream)
     if dist is not None:  # the one data-path collective: gather the tile buffers (padded to the largest shard)
-        frame = crt.shard.gather_frame(d_rgb.reshape(-1, 3), args.width, args.height, rank, world, dist)
+        frame = crt.shard.gather_frame(d_rgb.reshape(-1, 3).to(coll), args.width, args.height, rank, world, dist)
     barrier()
     elapsed = time.perf_counter() - t0
     st = r.stats()
     prof = r.profile_read()
     r.profile(False)
 
-    rays = torch.tensor([st.closest_hit, st.shadow_rays, st.camera_rays, st.vertices], dtype=torch.int64, device="cuda")
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    rays = torch.tensor([st.closest_hit, st.shadow_rays, st.camera_rays, st.vertices], dtype=torch.int64, device=coll)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll)
     if dist is not None:
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -170,7 +180,7 @@ def main():
             "mean_path_length": round(rays[3] / max(rays[2], 1), 3),
             "seconds": round(elapsed, 4),
             "spp_per_second": round(args.steps * spp_step / elapsed, 2),
-            "sharding": "16x16 pixel tiles round-robin over ranks; one RCCL all_gather of tile buffers" if world > 1 else "none",
+            "sharding": ("16x16 pixel tiles round-robin over ranks; one %s all_gather of tile buffers" % ("RCCL" if args.backend == "nccl" else "gloo (rehearsal)")) if world > 1 else "none",
         },
         "roofline": roofline,
         "cpu_baseline": cpu,
