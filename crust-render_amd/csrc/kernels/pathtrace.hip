@@ -102,10 +102,12 @@ __device__ __forceinline__ uint32_t dir_bin(float dx, float dy, float dz) {
   return (dx < 0.0f ? 1u : 0u) | (dy < 0.0f ? 2u : 0u) | (dz < 0.0f ? 4u : 0u);
 }
 // Prefix sums of a workgroup's kBins sub-segment counts (pre[kBins] = total); ends with a barrier.
+// The counts are read as volatile: in the fused kernel they were written earlier in the same launch by another wave
+// of this workgroup, so the read must be a fresh vector load, never a scalar-cache or hoisted one.
 __device__ __forceinline__ void bins_prefix(const uint32_t *counts, uint32_t *pre /* LDS, kBins + 1 */) {
   if (threadIdx.x == 0) {
     uint32_t acc = 0;
-    for (int b = 0; b < kBins; b++) { pre[b] = acc; acc += counts[b]; }
+    for (int b = 0; b < kBins; b++) { pre[b] = acc; acc += ((const volatile uint32_t *)counts)[b]; }
     pre[kBins] = acc;
   }
   __syncthreads();
@@ -203,9 +205,12 @@ __global__ void k_build_media(const CrtMaterial *materials, uint32_t n, DevMediu
 }
 
 // ---- generate: PathSampler::new(...).new_domain(tile), camera sample, camera ray (tracer.rs:559-585) ----
-__global__ __launch_bounds__(kBlock) void k_generate(Params P, PathSoA S, Counters *C, uint32_t sample_begin,
-                                                     uint32_t n_samples) {
-  __shared__ uint32_t sobol_tab[kSobolLdsWords];
+// Every stage body below is a device function working on the calling workgroup's own queue segment, with its big
+// LDS buffer passed in: the per-stage kernels hand it their own array, the fused kernel (k_path) one shared arena.
+constexpr int kArenaDwords = kEngineLdsDwords > kSobolLdsWords ? kEngineLdsDwords : kSobolLdsWords;
+
+__device__ __forceinline__ void generate_segment(const Params &P, const PathSoA &S, Counters *C, uint32_t sample_begin,
+                                                 uint32_t n_samples, uint32_t *sobol_tab /* kSobolLdsWords */) {
   sobol_tables_init(sobol_tab);
   // Camera samples are dealt to the workgroup segments in round-robin chunks of one workgroup's width: slot k of
   // segment b holds global sample g = ((k / 256) * G + b) * 256 + k % 256. Every segment is then a uniform
@@ -260,12 +265,16 @@ __global__ __launch_bounds__(kBlock) void k_generate(Params P, PathSoA S, Counte
     if (blockIdx.x == 0) atomicAdd(&C->stats[0], (unsigned long long)total);  // camera_rays (tracer.rs:585)
   }
 }
+__global__ __launch_bounds__(kBlock) void k_generate(Params P, PathSoA S, Counters *C, uint32_t sample_begin,
+                                                     uint32_t n_samples) {
+  __shared__ uint32_t sobol_tab[kSobolLdsWords];
+  generate_segment(P, S, C, sample_begin, n_samples, sobol_tab);
+}
 
 // ---- extend: World::intersect (rt_world.rs:207-232) for every live path ----
 template <bool STATS>
-__global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_extend(Params P, PathSoA S, HitSoA H, Counters *C, int cur, int first,
-                                                   CrtTravStats *tstats) {
-  __shared__ __attribute__((aligned(16))) uint32_t engine_lds[kEngineLdsDwords];
+__device__ __forceinline__ void extend_segment(const Params &P, const PathSoA &S, const HitSoA &H, Counters *C, int cur,
+                                               int first, CrtTravStats *tstats, uint32_t *engine_lds) {
   __shared__ uint32_t pre[kBins + 1];
   bins_prefix(&C->seg[cur][blockIdx.x * kBins], pre);
   const uint32_t n = pre[kBins];
@@ -301,14 +310,20 @@ __global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_extend(Params P, P
   if (err) atomicOr(&C->err, err);
   if (STATS) flush_stats(st, tstats, done);
 }
+template <bool STATS>
+__global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_extend(Params P, PathSoA S, HitSoA H, Counters *C, int cur, int first,
+                                                   CrtTravStats *tstats) {
+  __shared__ __attribute__((aligned(16))) uint32_t engine_lds[kEngineLdsDwords];
+  extend_segment<STATS>(P, S, H, C, cur, first, tstats, engine_lds);
+}
 
 // ---- shade: one iteration of trace_path's loop body for every live path (tracer.rs:1118-1530) ----
 // MEDIA: some material of the scene has an interior medium; scenes without one run the leaner instance (the medium
 // code costs k_shade 80 spilled VGPRs at three waves per SIMD).
 template <bool MEDIA>
-__global__ __launch_bounds__(kBlock, CRT_SHADE_WAVES) void k_shade(Params P, PathSoA S, PathSoA N, HitSoA H, ShadowSoA Q, Counters *C,
-                                                  int cur, float4 *staging) {
-  __shared__ uint32_t sobol_tab[kSobolLdsWords];
+__device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S, const PathSoA &N, const HitSoA &H,
+                                              const ShadowSoA &Q, Counters *C, int cur, float4 *staging,
+                                              uint32_t *sobol_tab /* kSobolLdsWords */) {
   __shared__ uint32_t lds_ctr[10];  // [1] shadow requests, [2..8] statistics
   __shared__ uint32_t out_n[kBins];  // survivors per direction bin
   __shared__ uint32_t pre[kBins + 1];
@@ -553,13 +568,18 @@ __global__ __launch_bounds__(kBlock, CRT_SHADE_WAVES) void k_shade(Params P, Pat
   if (threadIdx.x >= 1 && threadIdx.x <= 7 && lds_ctr[threadIdx.x + 1])
     atomicAdd(&C->stats[threadIdx.x], (unsigned long long)lds_ctr[threadIdx.x + 1]);
 }
+template <bool MEDIA>
+__global__ __launch_bounds__(kBlock, CRT_SHADE_WAVES) void k_shade(Params P, PathSoA S, PathSoA N, HitSoA H, ShadowSoA Q, Counters *C,
+                                                  int cur, float4 *staging) {
+  __shared__ uint32_t sobol_tab[kSobolLdsWords];
+  shade_segment<MEDIA>(P, S, N, H, Q, C, cur, staging, sobol_tab);
+}
 
 // ---- shadow: World::occluded (rt_world.rs:235-237) for the queue; unoccluded requests pay out ----
 template <bool STATS>
-__global__ __launch_bounds__(kBlock, CRT_SHADOW_WAVES) void k_shadow(Params P, PathSoA N, ShadowSoA Q, Counters *C, float4 *staging,
-                                                   CrtTravStats *tstats) {
-  __shared__ __attribute__((aligned(16))) uint32_t engine_lds[kEngineLdsDwords];
-  const uint32_t n = C->shadow[blockIdx.x];
+__device__ __forceinline__ void shadow_segment(const Params &P, const PathSoA &N, const ShadowSoA &Q, Counters *C,
+                                               float4 *staging, CrtTravStats *tstats, uint32_t *engine_lds) {
+  const uint32_t n = ((const volatile uint32_t *)C->shadow)[blockIdx.x];
   if (n == 0) return;  // uniform per workgroup
   __shared__ uint32_t next;
   if (threadIdx.x == 0) next = 0;
@@ -594,6 +614,47 @@ __global__ __launch_bounds__(kBlock, CRT_SHADOW_WAVES) void k_shadow(Params P, P
   run_traversal<true, STATS>(P.scene, engine_lds, 0.001f, err, st, fetch, emit);
   if (err) atomicOr(&C->err, err);
   if (STATS) flush_stats(st, tstats, done);
+}
+template <bool STATS>
+__global__ __launch_bounds__(kBlock, CRT_SHADOW_WAVES) void k_shadow(Params P, PathSoA N, ShadowSoA Q, Counters *C, float4 *staging,
+                                                   CrtTravStats *tstats) {
+  __shared__ __attribute__((aligned(16))) uint32_t engine_lds[kEngineLdsDwords];
+  shadow_segment<STATS>(P, N, Q, C, staging, tstats, engine_lds);
+}
+
+// ---- the whole path loop of one wavefront batch in ONE launch. Queue segments are private to their workgroup at
+// every stage (generate, extend, shade and shadow of segment b all run in workgroup b), so nothing but a workgroup
+// barrier separates the stages: no grid-wide barrier, no launch per bounce, and workgroups drift apart freely — while
+// one is shading (VALU-bound) its neighbours on the same SIMDs are traversing (latency-bound). A workgroup leaves as
+// soon as its segment is empty. LIT: the scene has lights and the strategy samples them (shadow stage present). ----
+template <bool MEDIA, bool LIT>
+__global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_path(Params P, PathSoA S0, PathSoA S1, HitSoA H, ShadowSoA Q, Counters *C,
+                                                 float4 *staging, uint32_t sample_begin, uint32_t n_samples) {
+  __shared__ __attribute__((aligned(16))) uint32_t arena[kArenaDwords];
+  __shared__ uint32_t live;
+  generate_segment(P, S0, C, sample_begin, n_samples, arena);
+  __syncthreads();
+  int cur = 0;
+  for (uint32_t it = 0; it <= P.max_depth; it++) {
+    const PathSoA &S = cur ? S1 : S0;
+    const PathSoA &N = cur ? S0 : S1;
+    extend_segment<false>(P, S, H, C, cur, it == 0 ? 1 : 0, nullptr, arena);
+    __syncthreads();  // hit records of this segment are complete; the arena changes hands
+    shade_segment<MEDIA>(P, S, N, H, Q, C, cur, staging, arena);
+    __syncthreads();
+    if (LIT) {
+      shadow_segment<false>(P, N, Q, C, staging, nullptr, arena);
+      __syncthreads();
+    }
+    cur = 1 - cur;
+    if (threadIdx.x == 0) {
+      uint32_t n = 0;
+      for (int b = 0; b < kBins; b++) n += ((const volatile uint32_t *)C->seg[cur])[blockIdx.x * kBins + b];
+      live = n;
+    }
+    __syncthreads();
+    if (live == 0) break;  // uniform: every path of this segment has ended
+  }
 }
 
 // ---- resolve: sum += color, in sample order; weight_sum += wx*wy = 1 (tracer.rs:599-600) ----
@@ -640,6 +701,7 @@ struct Renderer {
   CrtMaterial *d_materials = nullptr;
   DevMedium *d_media = nullptr;  // [n_materials] by geom_id, then [n_materials] by compact id
   bool has_media = false;
+  bool fused = true;  // CRT_FUSED=0: one launch per stage and bounce (per-stage timing, A/B)
   CrtLight *d_lights = nullptr;
   uint32_t *d_pixels = nullptr;
   int grid = 2048;
@@ -726,6 +788,20 @@ struct Renderer {
     {  // segment size for THIS batch size (buffers may be larger)
       const size_t total = (size_t)P.n_pix * n_samples;
       p.seg_cap = (uint32_t)(((total + (size_t)grid * kBlock - 1) / ((size_t)grid * kBlock)) * kBlock);
+    }
+    const bool lit = P.n_lights > 0 && P.strategy != CRT_STRATEGY_BSDF;
+    if (fused && !d_tstats) {  // one launch for the whole path loop (class 0 of the profile), then the film fold
+      timed(0, st, [&] {
+        if (has_media) {
+          if (lit) hipLaunchKernelGGL((k_path<true, true>), dim3(grid), dim3(kBlock), 0, st, p, S[0], S[1], H, Q, C, staging, sample_begin, n_samples);
+          else hipLaunchKernelGGL((k_path<true, false>), dim3(grid), dim3(kBlock), 0, st, p, S[0], S[1], H, Q, C, staging, sample_begin, n_samples);
+        } else {
+          if (lit) hipLaunchKernelGGL((k_path<false, true>), dim3(grid), dim3(kBlock), 0, st, p, S[0], S[1], H, Q, C, staging, sample_begin, n_samples);
+          else hipLaunchKernelGGL((k_path<false, false>), dim3(grid), dim3(kBlock), 0, st, p, S[0], S[1], H, Q, C, staging, sample_begin, n_samples);
+        }
+      });
+      timed(3, st, [&] { hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(kBlock), 0, st, staging, P.n_pix, n_samples, film); });
+      return CRT_HIP_OK(hipGetLastError()) ? CRT_OK : CRT_ERR_NO_DEVICE;
     }
     timed(3, st, [&] { hipLaunchKernelGGL(k_generate, dim3(grid), dim3(kBlock), 0, st, p, S[0], C, sample_begin, n_samples); });
     int cur = 0;
@@ -845,6 +921,7 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
   if (const char *e = getenv("CRT_GRID_MULT")) mult = atoi(e) > 0 ? atoi(e) : 3;  // tuning knob
   if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) r.grid = prop.multiProcessorCount * mult;
   if (r.grid > kMaxGrid) r.grid = kMaxGrid;
+  if (const char *e = getenv("CRT_FUSED")) r.fused = atoi(e) != 0;
   return R;
 }
 void crt_renderer_free(CrtRenderer *r) { delete r; }
