@@ -18,9 +18,10 @@ fixed as N grows ("weak": N GPUs advance the frame N times as many spp per step)
 the only collective is ONE RCCL all_gather of the per-rank tile buffers after the last step (inside the timed
 region), plus the 64-bit ray counters.
 
-roofline: for the dominant kernel (k_extend, the BVH4 closest-hit traversal): algorithmic bytes (SURVEY §8d
-formula, from the stats build of the same kernels on the same batch) over the HIP-event duration of its launches
-in the timed region, against the 8 TB/s HBM peak. cpu_baseline: the oracle (CPU restatement, "port") rendering a
+roofline: for the dominant kernel — k_path, which runs a whole batch (generate, every bounce's BVH4 traversal,
+shading and shadow stage) in one launch: algorithmic bytes (SURVEY §8d formulas; traversal counters from the stats
+build of the same stages on the same batch) over the HIP-event duration of its launches in the timed region, against
+the 8 TB/s HBM peak. `unfused_stage_ms_per_step` splits a step by stage (a second renderer with CRT_FUSED=0). cpu_baseline: the oracle (CPU restatement, "port") rendering a
 bounded sample of the same workload on this box's host cores.
 """
 import argparse
@@ -129,25 +130,53 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel (k_extend), N=1 figures of rank 0 ----
+    # ---- roofline of the dominant kernel, N=1 figures of rank 0 ----
+    # Default build: ONE kernel per step, k_path (generate + every bounce's traversal, shading and shadow stage of a
+    # workgroup-private queue segment). Algorithmic bytes per launch: the per-ray traversal
+    # formula summed over the closest-hit and the shadow rays of one batch (counters from the stats build of the
+    # same stages on the same batch) + 352 B per shaded vertex (path state 96 B each way + 160 B material record).
+    fused = os.environ.get("CRT_FUSED", "1") != "0"
     ext, sh = r.render_samples_stats(0, spp_step, stream)  # stats build, same batch shape; not timed
-    steps_bytes = ext.algorithmic_bytes() * args.steps    # every timed step runs the same batch shape
-    # (per-step counts differ only through the sample index; one batch is representative to < 1 %)
-    ext_ms, ext_n = prof["extend"]["ms"], prof["extend"]["launches"]
-    achieved = steps_bytes / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
+    trav_bytes = ext.algorithmic_bytes() + sh.algorithmic_bytes()
+    shade_bytes = 352 * (st.vertices // max(args.steps, 1))
+    launch_bytes = (trav_bytes + shade_bytes) if fused else ext.algorithmic_bytes()
+    k_ms, k_n = prof["extend"]["ms"], prof["extend"]["launches"]   # class 0: k_path when fused, k_extend otherwise
+    per_launch = launch_bytes * args.steps / max(k_n, 1)
+    achieved = per_launch / (k_ms / max(k_n, 1) * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    # per-stage split from a second renderer that launches every stage separately (2 untimed steps)
+    stage = None
+    if fused:
+        os.environ["CRT_FUSED"] = "0"
+        try:
+            r2, _ = crt.load_usda(path, args.width, args.height, args.depth, rank=rank, world=world)
+            r2.render_samples(0, spp_step, stream)
+            torch.cuda.synchronize()
+            r2.profile(True)
+            for k in range(2):
+                r2.render_samples(k * spp_step, spp_step, stream)
+            torch.cuda.synchronize()
+            p2 = r2.profile_read()
+            stage = {k: round(v["ms"] / 2, 3) for k, v in p2.items()}
+            stage["extend_algorithmic_gb_s"] = round(ext.algorithmic_bytes() / (p2["extend"]["ms"] / 2 * 1e-3) / 1e9, 1)
+            del r2
+        finally:
+            os.environ["CRT_FUSED"] = "1"
     roofline = {
-        "kernel": "k_extend (BVH4 closest-hit traversal)",
+        "kernel": "k_path (one launch per batch: generate + BVH4 traversal + shading + shadow per queue segment)" if fused
+                  else "k_extend (BVH4 closest-hit traversal)",
         "bound": "hbm",
         "achieved": round(achieved, 2),
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5),
-        "traffic": _traffic_from_profile(),
-        "launches": ext_n,
-        "avg_launch_ms": round(ext_ms / max(ext_n, 1), 5),
-        "bytes_per_launch": int(steps_bytes / max(ext_n, 1)),
-        "bytes_per_ray": round(ext.algorithmic_bytes() / max(int(ext.rays), 1), 1),
+        "traffic": _traffic_from_profile(fused),
+        "launches": k_n,
+        "avg_launch_ms": round(k_ms / max(k_n, 1), 5),
+        "bytes_per_launch": int(per_launch),
+        "traversal_bytes_per_ray": round(ext.algorithmic_bytes() / max(int(ext.rays), 1), 1),
+        "shading_bytes_per_vertex": 352,
         "kernel_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
+        "unfused_stage_ms_per_step": stage,
     }
 
     cpu = None
@@ -190,9 +219,9 @@ def main():
         dist.destroy_process_group()
 
 
-def _traffic_from_profile():
-    """HBM bytes per k_extend launch from the committed rocprofv3 --pmc passes (profiles/*_pmc.json), or null."""
-    p = os.path.join(ROOT, "profiles", "r01_pmc_extend.json")
+def _traffic_from_profile(fused):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes, or null."""
+    p = os.path.join(ROOT, "profiles", "r01_pmc_path.json" if fused else "r01_pmc_extend.json")
     if os.path.exists(p):
         try:
             with open(p) as f:

@@ -232,7 +232,9 @@ int crt_film_clear(CrtRenderer *r, void *stream);
 /* Counters since the last clear (syncs the stream the batches ran on). */
 int crt_render_stats(CrtRenderer *r, CrtRayStats *out);
 /* Live HIP-event timing of the kernels launched by crt_render_samples since the last reset, by class:
- * 0 = extend (closest-hit traversal), 1 = shade, 2 = shadow (occlusion traversal), 3 = other.
+ * 0 = extend (closest-hit traversal) — or, by default, the fused path-loop kernel that runs generate, extend, shade
+ * and shadow of a whole batch in one launch (environment CRT_FUSED=0 launches every stage separately) —
+ * 1 = shade, 2 = shadow (occlusion traversal), 3 = other.
  * out_ms[k] = summed duration, out_launches[k] = launches. Enabled by crt_renderer_profile(r, 1). */
 int crt_renderer_profile(CrtRenderer *r, int enable);
 int crt_renderer_profile_read(CrtRenderer *r, double out_ms[4], uint64_t out_launches[4]);
