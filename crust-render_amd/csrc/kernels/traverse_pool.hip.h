@@ -2,7 +2,7 @@
 // step the whole wave executes ONE kind of work — node expansion, packet test, scalar primitive, instance exit,
 // emit, or fetch — for the lanes that have a ray waiting for exactly that.
 //
-// Why: with one ray per lane (traverse.hip.h) incoherent rays sit in different phases of their traversal, and the
+// Why: with one ray per lane (the first engine of this repository, commit 51c24ac) incoherent rays sit in different phases of their traversal, and the
 // wave pays for every phase with the few lanes that are in it: measured on cornellbox 1080p, 35 % of the lanes are
 // live in a node expansion, 38 % in a packet test, 5 % in an instance entry or exit (CrtTravStats::phase_lanes).
 // Replaying the oracle's per-ray work traces through both schedulers (profiles/simulate_scheduling.py) predicts
@@ -699,34 +699,24 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
   }
 }
 
-// ---- engine selection: CRT_POOL_ROWS rays per lane, phase-scheduled (default 2); 0 = one ray per lane (traverse.hip.h) ----
+// ---- the engine as the kernels use it ----
 #ifndef CRT_POOL_ROWS
 #define CRT_POOL_ROWS 2
 #endif
 #ifndef CRT_POOL_NODES
 #define CRT_POOL_NODES 32
 #endif
-#if CRT_POOL_ROWS > 0
 constexpr int kPoolNodes = CRT_POOL_NODES;  // nodes of the top of the tree staged in LDS per workgroup
 constexpr int kEngineLdsDwords = (kBlock / 64) * pool_lds_dwords<CRT_POOL_ROWS>() + kPoolNodes * kLdsNodeStride;
-#else
-constexpr int kEngineLdsDwords = kStackLds * kBlock + kLdsNodes * kLdsNodeStride;
-#endif
-// Runs the selected engine for one workgroup. `lds` = kEngineLdsDwords dwords, 16-byte aligned. Contains a
-// workgroup barrier: call from uniform control flow, after shared variables the callbacks use are initialised.
+// Runs the traversal for one workgroup. `lds` = kEngineLdsDwords dwords, 16-byte aligned. Contains a workgroup
+// barrier: call from uniform control flow, after the shared variables the callbacks use are initialised.
 template <bool ANY, bool STATS, class Fetch, class Emit>
 __device__ __forceinline__ void run_traversal(const DevScene &S, uint32_t *lds, float t_min, uint32_t &err, LaneStats &st,
                                               Fetch fetch, Emit emit) {
-#if CRT_POOL_ROWS > 0
   uint32_t *lds_nodes = lds + (kBlock / 64) * pool_lds_dwords<CRT_POOL_ROWS>();
   const uint32_t n_lds = stage_nodes(S, lds_nodes, kPoolNodes);  // ends with a barrier
   traverse_pool<ANY, STATS, CRT_POOL_ROWS>(S, lds + (threadIdx.x >> 6) * pool_lds_dwords<CRT_POOL_ROWS>(), t_min, lds_nodes,
                                            n_lds, err, st, fetch, emit);
-#else
-  uint32_t *lds_nodes = lds + kStackLds * kBlock;
-  const uint32_t n_lds = stage_nodes(S, lds_nodes);  // ends with a barrier
-  traverse_stream<ANY, STATS>(S, lds + threadIdx.x, lds_nodes, n_lds, err, st, fetch, emit);
-#endif
 }
 
 }  // namespace dev

@@ -84,3 +84,25 @@ def test_tile_shards_reassemble_the_single_gpu_image(crt):
         img[idx] = r.film()
     assert seen.all()
     assert np.array_equal(img.reshape(48, 80, 3).view(np.uint32), full.image().view(np.uint32))
+
+
+def test_fused_and_per_stage_launches_agree(crt, tmp_path):
+    """The fused path-loop kernel (default) and the one-launch-per-stage path (CRT_FUSED=0) are the same device
+    functions: identical image and counters, on a lit scene with interior media."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, numpy as np; sys.path.insert(0, %r); import torch\n"
+        "from __graft_entry__ import load_package; crt = load_package()\n"
+        "r, _ = crt.load_usda(os.path.join(%r, 'scenes', 'openpbr_showcase.usda'), 96, 54, 12)\n"
+        "r.render_samples(0, 8); torch.cuda.synchronize(); st = r.stats()\n"
+        "np.save(sys.argv[1], r.image()); print(st.closest_hit, st.shadow_rays, st.vertices, st.rr_killed)\n" % (ROOT, ROOT))
+    outs = []
+    for fused in ("1", "0"):
+        path = str(tmp_path / ("img%s.npy" % fused))
+        env = dict(os.environ, CRT_FUSED=fused)
+        res = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs.append((np.load(path), res.stdout.strip().splitlines()[-1]))
+    assert outs[0][1] == outs[1][1]
+    assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
