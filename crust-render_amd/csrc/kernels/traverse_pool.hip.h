@@ -256,28 +256,13 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
             key[l] = tn;
             ent[l] = on ? (child[l] | (((flags >> (4 + l)) & 1u) ? kLeafTag : 0u)) : kInvalid;  // kInvalid = lane off
           }
-          if (!ANY) {
-            // Stable insertion sort of the hit lanes by entry distance (bvh.rs:472-486); off lanes sort last.
-#pragma unroll
-            for (int l = 0; l < 4; l++)
-              if (ent[l] == kInvalid) key[l] = __builtin_inff();
-            auto after = [&](int a, int b) {
-              const bool offa = ent[a] == kInvalid, offb = ent[b] == kInvalid;
-              return (key[a] > key[b]) || (key[a] == key[b] && offa && !offb);
-            };
-            auto swp = [&](int a, int b) {
-              const float k = key[a]; key[a] = key[b]; key[b] = k;
-              const uint32_t x = ent[a]; ent[a] = ent[b]; ent[b] = x;
-            };
-            if (after(0, 1)) swp(0, 1);
-            if (after(1, 2)) { swp(1, 2); if (after(0, 1)) swp(0, 1); }
-            if (after(2, 3)) { swp(2, 3); if (after(1, 2)) { swp(1, 2); if (after(0, 1)) swp(0, 1); } }
-          }
           // Stack image after this node, bottom to top. Ordered traversal: inner lanes far to near, then leaf
           // lanes far to near on top, so they pop first and near-first — the reference's "leaf lanes now, near
-          // first; inner lanes pushed far to near" (bvh.rs:488-505). Any-hit: the hit lanes in lane order
-          // (bvh.rs:596-606). Every entry's final position is known up front, so the entries are stored with
-          // independent predicated writes, and the top one — the entry the ray visits next — stays in a register.
+          // first; inner lanes pushed far to near" (bvh.rs:488-505) after its stable insertion sort of the hit
+          // lanes by entry distance (bvh.rs:472-486: equal keys keep lane order). Any-hit: the hit lanes in lane
+          // order (bvh.rs:596-606). Every entry's final position follows from the six pairwise "is nearer"
+          // relations, so the entries are stored with independent predicated writes — no sorting network — and
+          // the top one, the entry the ray visits next, stays in a register.
           uint32_t on[4], lf4[4], pos[4];
 #pragma unroll
           for (int i = 0; i < 4; i++) { on[i] = ent[i] != kInvalid ? 1u : 0u; lf4[i] = (on[i] && (ent[i] & kLeafTag)) ? 1u : 0u; }
@@ -286,13 +271,26 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
             pos[0] = 0; pos[1] = on[0]; pos[2] = on[0] + on[1]; pos[3] = on[0] + on[1] + on[2];
             n_tot = pos[3] + on[3];
           } else {
-            const uint32_t in0 = on[0] - lf4[0], in1 = on[1] - lf4[1], in2 = on[2] - lf4[2], in3 = on[3] - lf4[3];
-            const uint32_t n_in = in0 + in1 + in2 + in3;
-            // entries are sorted near (0) to far (3); an entry sits above every farther entry of its kind
-            pos[3] = lf4[3] ? n_in : 0u;
-            pos[2] = lf4[2] ? n_in + lf4[3] : in3;
-            pos[1] = lf4[1] ? n_in + lf4[3] + lf4[2] : in3 + in2;
-            pos[0] = lf4[0] ? n_in + lf4[3] + lf4[2] + lf4[1] : in3 + in2 + in1;
+            // nr[i][j] (i < j): lane i is visited before lane j  <=>  key_i <= key_j (stable)
+            const uint32_t n01 = key[0] <= key[1], n02 = key[0] <= key[2], n03 = key[0] <= key[3];
+            const uint32_t n12 = key[1] <= key[2], n13 = key[1] <= key[3], n23 = key[2] <= key[3];
+            uint32_t in4[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) in4[i] = on[i] - lf4[i];
+            const uint32_t n_in = in4[0] + in4[1] + in4[2] + in4[3];
+            // entries of the same kind that are FARTHER than lane i sit below it
+            const uint32_t f0k[3] = {n01, n02, n03};                    // lane 0 nearer than 1, 2, 3
+            const uint32_t f1k[3] = {1u - n01, n12, n13};               // lane 1 nearer than 0, 2, 3
+            const uint32_t f2k[3] = {1u - n02, 1u - n12, n23};          // lane 2 nearer than 0, 1, 3
+            const uint32_t f3k[3] = {1u - n03, 1u - n13, 1u - n23};     // lane 3 nearer than 0, 1, 2
+            pos[0] = lf4[0] ? n_in + (f0k[0] & lf4[1]) + (f0k[1] & lf4[2]) + (f0k[2] & lf4[3])
+                            : (f0k[0] & in4[1]) + (f0k[1] & in4[2]) + (f0k[2] & in4[3]);
+            pos[1] = lf4[1] ? n_in + (f1k[0] & lf4[0]) + (f1k[1] & lf4[2]) + (f1k[2] & lf4[3])
+                            : (f1k[0] & in4[0]) + (f1k[1] & in4[2]) + (f1k[2] & in4[3]);
+            pos[2] = lf4[2] ? n_in + (f2k[0] & lf4[0]) + (f2k[1] & lf4[1]) + (f2k[2] & lf4[3])
+                            : (f2k[0] & in4[0]) + (f2k[1] & in4[1]) + (f2k[2] & in4[3]);
+            pos[3] = lf4[3] ? n_in + (f3k[0] & lf4[0]) + (f3k[1] & lf4[1]) + (f3k[2] & lf4[2])
+                            : (f3k[0] & in4[0]) + (f3k[1] & in4[1]) + (f3k[2] & in4[2]);
             n_tot = n_in + lf4[0] + lf4[1] + lf4[2] + lf4[3];
           }
           if (n_tot == 0) {
