@@ -44,9 +44,36 @@ def random_rays(n, extent, seed=1):
     return rays
 
 
+def uv_sphere_np(center, radius, segs, rings):
+    """Vectorised tessellation with the probe's topology (ray_throughput.rs:18-48); values are numpy's sin/cos, so
+    this scene is for throughput only, not parity."""
+    r = np.arange(rings + 1, dtype=np.float64)[:, None] / rings * np.pi
+    t = np.arange(segs + 1, dtype=np.float64)[None, :] / segs * 2.0 * np.pi
+    d = np.stack([np.sin(r) * np.cos(t), np.cos(r) * np.ones_like(t), np.sin(r) * np.sin(t)], axis=-1).reshape(-1, 3)
+    v = (np.asarray(center, dtype=np.float64) + radius * d).astype(np.float32)
+    row = segs + 1
+    rr, ss = np.meshgrid(np.arange(rings), np.arange(segs), indexing="ij")
+    a, b, c, e = rr * row + ss, rr * row + ss + 1, (rr + 1) * row + ss + 1, (rr + 1) * row + ss
+    idx = np.stack([np.stack([a, b, c], -1), np.stack([a, c, e], -1)], axis=2).reshape(-1, 3).astype(np.uint32)
+    return v, idx
+
+
+def big_tri_spheres(api, segs, rings):
+    """The tri_spheres layout (27 spheres at 2.5 spacing) at a tessellation whose BVH does not fit the caches."""
+    b = api.SceneBuilder()
+    for x in (-1, 0, 1):
+        for y in (-1, 0, 1):
+            for z in (-1, 0, 1):
+                v, i = uv_sphere_np((2.5 * x, 2.5 * y, 2.5 * z), 1.0, segs, rings)
+                b.attach_triangles(v, i)
+    return b.commit()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rays", type=int, default=1 << 24)
+    ap.add_argument("--big", type=int, default=0, metavar="SEGS",
+                    help="also run tri_spheres at SEGS x SEGS/2 quads per sphere (e.g. 512 -> 7.1 M triangles)")
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--no-oracle", action="store_true")
     args = ap.parse_args()
@@ -58,9 +85,20 @@ def main():
     crt = load_package()
     inf = float("inf")
     out = {"device": torch.cuda.get_device_name(0), "rays": args.rays, "reps": args.reps, "scenes": {}}
-    for name in ("tri_spheres", "sphere_grid", "instances"):
-        make, extent = scenes.ALL[name]
-        scene = make(crt)
+    names = ["tri_spheres", "sphere_grid", "instances"] + (["tri_spheres_big"] if args.big else [])
+    for name in names:
+        if name == "tri_spheres_big":
+            make, extent = (lambda api: big_tri_spheres(api, args.big, args.big // 2)), 6.0
+            t0 = time.perf_counter()
+            scene = make(crt)
+            fp = scene.memory_footprint() if hasattr(scene, "memory_footprint") else None
+            out["big_build_seconds"] = round(time.perf_counter() - t0, 2)
+            out["big_triangles"] = 27 * args.big * (args.big // 2) * 2
+            if fp is not None:
+                out["big_device_bytes"] = int(sum(fp.values()))
+        else:
+            make, extent = scenes.ALL[name]
+            scene = make(crt)
         d_rays = crt.rays_to_device(random_rays(args.rays, extent))
         d_hits = torch.empty(args.rays * 40, dtype=torch.uint8, device="cuda")
         d_occ = torch.empty(args.rays, dtype=torch.int32, device="cuda")
@@ -89,8 +127,8 @@ def main():
                    "algorithmic_gb_s": round(st.algorithmic_bytes() / (ms * 1e-3) / 1e9, 1),
                    "nodes_per_ray": round((st.nodes[0] + st.nodes[1]) / args.rays, 2),
                    "lane_utilisation": {k: round(u, 3) for k, (w, u) in st.utilisation().items() if w},
-                   "published_cpu_1t_mray_s": round(4096 / PUBLISHED_MS[(name, query)] / 1e3, 2)}
-            if not args.no_oracle:
+                   "published_cpu_1t_mray_s": round(4096 / PUBLISHED_MS[(name, query)] / 1e3, 2) if (name, query) in PUBLISHED_MS else None}
+            if not args.no_oracle and name != "tri_spheres_big":
                 import ora
                 o_scene = make(ora)
                 rays = fx.ray_batch(4096, extent)
