@@ -82,7 +82,8 @@ def main():
 
     crt = load_package()
     crt.lib()
-    path = os.path.join(ROOT, "scenes", args.scene + ".usda")
+    # a sample scene file, or a labelled synthetic scene ("synthetic:city[:side]", crust-render_amd/synthetic.py)
+    path = args.scene if args.scene.startswith("synthetic:") else os.path.join(ROOT, "scenes", args.scene + ".usda")
     r, desc = crt.load_usda(path, args.width, args.height, args.depth, rank=rank, world=world)
     spp_step = args.spp_per_step * world
     stream = torch.cuda.current_stream()
@@ -169,7 +170,8 @@ def main():
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5),
-        "traffic": _traffic_from_profile(fused),
+        # the committed PMC passes were taken on the default workload only
+        "traffic": _traffic_from_profile(fused) if (args.scene == "cornellbox" and (args.width, args.height) == (1920, 1080)) else None,
         "launches": k_n,
         "avg_launch_ms": round(k_ms / max(k_n, 1), 5),
         "bytes_per_launch": int(per_launch),
@@ -195,10 +197,12 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic-free: the reference's own sample scene file (scenes/%s.usda), seeded sampler, frame 0" % args.scene,
+        "data": ("synthetic scene %s (generated in code, NOT a reference file), seeded sampler, frame 0" % args.scene)
+                if args.scene.startswith("synthetic:") else
+                ("the reference's own sample scene file (scenes/%s.usda), seeded sampler, frame 0" % args.scene),
         "config": {
-            "workload": "samples/%s.usda %dx%d, %d spp per step per GPU-share (x%d GPUs), depth %d, triangle r=1, "
-                        "variance 0; %d steps = %d spp" % (args.scene, args.width, args.height, args.spp_per_step, world,
+            "workload": "%s %dx%d, %d spp per step per GPU-share (x%d GPUs), depth %d, triangle r=1, "
+                        "variance 0; %d steps = %d spp" % (args.scene if args.scene.startswith("synthetic:") else "samples/%s.usda" % args.scene, args.width, args.height, args.spp_per_step, world,
                                                            r.settings.max_depth, args.steps, args.steps * spp_step),
             "spp_per_step": spp_step,
             "paths_per_step_per_gpu": r.n_pix * spp_step,

@@ -620,10 +620,17 @@ class Renderer:
 
 
 def load_usda(path, width=None, height=None, max_depth=None, rank=0, world=1):
-    """Scene::from_usd (scene.rs / usd_import.rs:287-424) for the text sample scenes -> (Renderer, desc)."""
+    """Scene::from_usd (scene.rs / usd_import.rs:287-424) for the text sample scenes -> (Renderer, desc).
+    `path` may also name a synthetic scene: "synthetic:city" or "synthetic:city:<side>" (synthetic.py)."""
     from . import usda
     import sys
-    desc = usda.load(path, width, height)
+    if str(path).startswith("synthetic:"):
+        from . import synthetic
+        parts = str(path).split(":")
+        kw = dict(side=int(parts[2])) if len(parts) > 2 else {}
+        desc = getattr(synthetic, parts[1])(width or 640, height or 360, **kw)
+    else:
+        desc = usda.load(path, width, height)
     me = sys.modules[__name__]
     scene, materials, protos = usda.build_world(desc, me, default_material)
     s = desc.settings
@@ -636,3 +643,4 @@ def load_usda(path, width=None, height=None, max_depth=None, rank=0, world=1):
 
 from . import usda  # noqa: E402,F401  (the minimal USDA reader)
 from . import shard  # noqa: E402,F401  (pixel-tile sharding + the tile gather)
+from . import synthetic  # noqa: E402,F401  (scenes built in code: the labelled stand-in for BASELINE config 5)

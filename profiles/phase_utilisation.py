@@ -3,7 +3,8 @@ sys.path.insert(0, os.getcwd())
 import torch
 from __graft_entry__ import load_package
 crt = load_package()
-r, desc = crt.load_usda("scenes/cornellbox.usda", 1920, 1080, None)
+scene = sys.argv[1] if len(sys.argv) > 1 else "scenes/cornellbox.usda"
+r, desc = crt.load_usda(scene, 1920, 1080, None)
 ext, sh = r.render_samples_stats(0, 8)
 print("rays", int(ext.rays), "bytes/ray", ext.algorithmic_bytes() / int(ext.rays))
 print(ext.as_dict())

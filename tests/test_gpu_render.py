@@ -45,6 +45,20 @@ def test_image_and_counters_identical_to_oracle(crt, name, w, h, spp, depth):
     assert bad.shape[0] == 0, f"{name}: {bad.shape[0]} differing components, first {bad[:3]}"
 
 
+def test_synthetic_city_identical_to_oracle(crt):
+    """The labelled stand-in for BASELINE config 5 (instancing-heavy): 576 instances of four prototypes, two sphere
+    lights, five material variants — image and counters identical to the oracle."""
+    import torch
+    r, desc = crt.load_usda("synthetic:city:24", 96, 54, 6)
+    r.render_samples(0, 4)
+    torch.cuda.synchronize()
+    img, st = r.image(), r.stats()
+    oimg, ost = ora_world.OracleRenderer(desc, crt.usda, max_depth=6).render(4, forward=1)
+    for f, _t in ora.RayStats._fields_:
+        assert getattr(st, f) == getattr(ost, f), f
+    assert st.shadow_rays > 0 and np.array_equal(img.view(np.uint32), oimg.view(np.uint32))
+
+
 def test_batches_accumulate_in_sample_order(crt):
     """Rendering 8 spp as 1 batch or as 4 batches of 2 must give the same bits (sum += color in sample order)."""
     a, *_ = _both(crt, "veach_mis", 64, 36, 8, 8, batch=8)
