@@ -1,25 +1,28 @@
-// Wavefront path tracer for gfx950: the surface arm of crust-core's integrator as data-parallel stages.
+// Wavefront path tracer for gfx950: crust-core's integrator (surface arm + carried interior media) as data-parallel
+// stages over device-resident queues.
 //
-// What it computes: crates/crust-core/src/tracer.rs:515-636 (render_pixel), :1086-1558 (trace_path, surface
-// arm), :930-953 (bounce_emission_weight), :1016-1035 (shadow test), :85-104 (MIS weights), :1478-1490
-// (Russian roulette), :1327-1340 (sky), rt_world.rs:207-237, light.rs:421-440 — with the backward gather
-// (tracer.rs:1537-1557) restated as the algebraically identical forward accumulation
-//     L += beta * w * emitted      (bounce-hit emission, weighted for the previous vertex)
-//     L += beta * emit_here        (primary vertex only)
-//     L += beta * nee              (after the shadow ray)
-//     beta *= value * cos / pdf    (then / p_survive under roulette)
-// in exactly that order, which is the order the CPU oracle's forward mode uses (oracle/ora_pt.c), so the
-// two agree bit for bit.
+// What it computes: crates/crust-core/src/tracer.rs:515-636 (render_pixel), :1086-1558 (trace_path: surface arm,
+// :1159-1165 / :1256-1319 / :1352-1360 carried medium), :930-953 (bounce_emission_weight), :1016-1035 (shadow
+// test), :85-104 (MIS weights), :1478-1490 (Russian roulette), :1327-1340 (sky), rt_world.rs:207-237,
+// light.rs:421-440 — with the backward gather (tracer.rs:1537-1557) restated as the algebraically identical forward
+// accumulation
+//     L += beta * (atten * emitted) * w     (bounce-hit emission, weighted for the previous vertex)
+//     L += (beta * atten) * emit_here       (primary vertex / after a medium scatter)
+//     L += (beta * atten) * nee             (after the shadow ray)
+//     beta *= atten * value * cos / pdf     (then / p_survive under roulette)
+// in exactly that order, which is the order the CPU oracle's forward mode uses, so the two agree bit for bit.
 //
-// Stages per bounce, each a persistent grid-stride launch over a device-resident queue (no host sync):
-//   generate : camera samples -> path state (SoA), one slot per (pixel, sample)
-//   extend   : closest-hit traversal of the live paths              -> hit records
-//   shade    : emission + MIS, light sampling -> shadow queue, BSDF sampling, roulette;
-//              survivors are compacted into the other state buffer with a wave ballot + prefix popcount
-//              and ONE atomic per wave; finished paths write their radiance to the film staging plane
-//   shadow   : any-hit traversal of the shadow queue; unoccluded requests add their contribution
+// Stages (device functions; k_path runs them all for a workgroup-private queue segment in one launch, the k_*
+// kernels one at a time — no host sync either way):
+//   generate : camera samples -> path state (SoA), one slot per (pixel, sample), dealt to the segments round-robin
+//   extend   : closest-hit traversal of the segment's live paths            -> hit records
+//   shade    : medium free flight, emission + MIS, light sampling -> shadow queue, BSDF sampling, roulette;
+//              survivors are compacted into the other state buffer of the SAME segment with a wave ballot +
+//              popcount prefix and an LDS counter (no global atomics); finished paths write their radiance to the
+//              film staging plane
+//   shadow   : any-hit traversal of the segment's shadow queue; unoccluded requests add their contribution
 //   resolve  : staging planes are folded into the film in sample order (sum += color, tracer.rs:599)
-// Path state is struct-of-arrays so every stage's loads and stores are unit-stride across a wave.
+// Path state is struct-of-arrays of 16-byte records, so every stage's loads and stores are unit-stride across a wave.
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
