@@ -342,10 +342,59 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
   sobol_tables_init(sobol_tab);  // ends with a workgroup barrier
   const uint32_t seg0 = blockIdx.x * P.seg_cap;  // shadow queue: one unbinned segment per workgroup
   uint32_t s_closest = 0, s_shadow = 0, s_vertices = 0, s_rr_t = 0, s_rr_k = 0, s_esc = 0, s_depth = 0;
-  const uint32_t rounds = (n + kBlock - 1) / kBlock;
-  for (uint32_t round = 0; round < rounds; round++) {
-    const uint32_t k_in = round * kBlock + threadIdx.x;
-    const bool active = k_in < n;
+  // Two kinds of work per path: a ray that escaped just adds the sky and ends (cheap), everything else runs the full
+  // vertex (expensive). Mixed in one wave the escaped lanes would idle through the vertex code — a third of the
+  // rays on an open scene — so the segment is swept in two interleaved steps: CLASSIFY takes the next 256 paths,
+  // finishes the escaped ones on the spot and appends the others to a ring of pending indices in LDS; SHADE takes
+  // 256 pending paths at a time (fewer only when the input is exhausted), so the vertex code runs on full waves.
+  constexpr uint32_t kRing = 2 * kBlock;
+  __shared__ uint32_t ring[kRing];
+  __shared__ uint32_t ring_tail;  // entries ever appended (head is tracked in registers: uniform)
+  if (threadIdx.x == 0) ring_tail = 0;
+  __syncthreads();
+  uint32_t next_in = 0, head = 0;
+  for (;;) {
+    uint32_t tail = ring_tail;  // uniform: read between two barriers, nobody appends meanwhile
+    __syncthreads();
+    // ---- CLASSIFY while fewer than a workgroup's worth of vertices is pending and input remains ----
+    while (tail - head < (uint32_t)kBlock && next_in < n) {
+      const uint32_t k_c = next_in + threadIdx.x;
+      next_in += kBlock;
+      bool pending = false;
+      if (k_c < n) {
+        const uint32_t i_c = bin_slot(k_c, pre, P.seg_cap);
+        const uint4 D = S.d[i_c];
+        const uint32_t hg = H.geom[i_c];
+        const int remaining = (int)(D.z >> 16);
+        const bool carries_medium = MEDIA && (D.w >> kMediumShift) != 0;
+        if (hg == kInvalid && remaining > 0 && !carries_medium) {
+          // tracer.rs:1321-1342: background = sky gradient (no light at infinity in scope); the path ends here
+          const float4 A = S.a[i_c], B = S.b[i_c], Cc = S.c[i_c];
+          const V3 rd = v3(A.w, B.x, B.y), beta = v3(B.z, B.w, Cc.x);
+          V3 L = v3(Cc.y, Cc.z, Cc.w);
+          s_closest++;
+          s_esc++;
+          const V3 unit_direction = normalize(rd);
+          const float t = 0.5f * (unit_direction.y + 1.0f);
+          const V3 background = splat(0.0f) + (v3(1.0f, 1.0f, 1.0f) * (1.0f - t) + v3(0.5f, 0.7f, 1.0f) * t);
+          L = L + beta * background;
+          staging[(D.w & 0xffffu) * P.n_pix + D.y] = make_float4(L.x, L.y, L.z, 0.0f);
+        } else {
+          pending = true;
+        }
+      }
+      const uint32_t at = seg_append(pending, &ring_tail);
+      if (pending) ring[at % kRing] = k_c;
+      __syncthreads();
+      tail = ring_tail;
+      __syncthreads();
+    }
+    if (tail == head) break;  // uniform: input exhausted and nothing pending
+    // ---- SHADE up to a workgroup's worth of pending vertices ----
+    const uint32_t take = tail - head < (uint32_t)kBlock ? tail - head : (uint32_t)kBlock;
+    const bool active = threadIdx.x < take;
+    const uint32_t k_in = active ? ring[(head + threadIdx.x) % kRing] : 0;
+    head += take;
     const uint32_t i = active ? bin_slot(k_in, pre, P.seg_cap) : 0;
     bool alive = false, want_shadow = false;
     V3 L = splat(0.0f), beta = splat(1.0f);
@@ -556,6 +605,7 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
       Q.b[q] = make_float4(sh_d.x, sh_d.y, sh_d.z, time);
       Q.c[q] = make_float4(sh_c.x, sh_c.y, sh_c.z, __uint_as_float(alive ? j : (kFilmTarget | film_idx)));
     }
+    __syncthreads();  // every lane has read its ring entry before CLASSIFY appends again
   }
   add_stat(&lds_ctr[2], s_closest); add_stat(&lds_ctr[3], s_shadow); add_stat(&lds_ctr[4], s_vertices);
   add_stat(&lds_ctr[5], s_rr_t); add_stat(&lds_ctr[6], s_rr_k); add_stat(&lds_ctr[7], s_esc);
