@@ -103,13 +103,14 @@ def main():
     r.profile(True)
     n_pix_total = args.width * args.height
     d_rgb = torch.empty(r.n_pix * 3, dtype=torch.float32, device="cuda")
+    plan = crt.shard.GatherPlan(args.width, args.height, world, coll) if dist is not None else None
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         r.render_samples(k * spp_step, spp_step, stream)
     r.film_to(d_rgb, stream)
     if dist is not None:  # the one data-path collective: gather the tile buffers (padded to the largest shard)
-        frame = crt.shard.gather_frame(d_rgb.reshape(-1, 3).to(coll), args.width, args.height, rank, world, dist)
+        frame = plan.gather(d_rgb.reshape(-1, 3).to(coll), dist)
     barrier()
     elapsed = time.perf_counter() - t0
     st = r.stats()

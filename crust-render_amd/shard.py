@@ -28,22 +28,32 @@ def padded_count(width, height, world):
     return ((tiles * 256 + 255) // 256) * 256
 
 
+class GatherPlan:
+    """Everything of the tile gather that does not depend on the pixels: per-rank index tensors and the send /
+    receive buffers, built once (outside any timed region)."""
+
+    def __init__(self, width, height, world, device):
+        import torch
+        self.width, self.height, self.world = width, height, world
+        self.n_max = padded_count(width, height, world)
+        self.idx = [torch.from_numpy(shard_pixels(width, height, r, world).astype(np.int64)).to(device) for r in range(world)]
+        self.send = torch.zeros(self.n_max * 3, dtype=torch.float32, device=device)
+        self.recv = torch.empty(world * self.n_max * 3, dtype=torch.float32, device=device) if world > 1 else self.send
+        self.frame = torch.zeros(height * width, 3, dtype=torch.float32, device=device)
+
+    def gather(self, film_local, dist=None):
+        """film_local: [n_owned, 3] of this rank (same device as the plan). ONE all_gather_into_tensor, then one
+        indexed store per rank's shard. Returns the full frame [height*width, 3] (buffer order: row 0 = bottom)."""
+        self.send[: film_local.numel()] = film_local.reshape(-1)
+        if self.world > 1 and dist is not None:
+            dist.all_gather_into_tensor(self.recv, self.send)
+        recv = self.recv.reshape(self.world, self.n_max, 3)
+        for r in range(self.world):
+            self.frame[self.idx[r]] = recv[r, : self.idx[r].numel()]
+        return self.frame
+
+
 def gather_frame(film_local, width, height, rank, world, dist=None):
-    """film_local: torch tensor [n_owned, 3] (any device) of this rank's pixel means in shard_pixels order.
-    Returns the full frame [height*width, 3] on every rank (buffer order: row 0 = bottom). With world == 1 (or
-    dist None) it is a local scatter; otherwise ONE all_gather_into_tensor of padded per-rank buffers."""
-    import torch
-    n_max = padded_count(width, height, world)
-    send = torch.zeros(n_max * 3, dtype=torch.float32, device=film_local.device)
-    send[: film_local.numel()] = film_local.reshape(-1)
-    if world > 1 and dist is not None:
-        recv = torch.empty(world * n_max * 3, dtype=torch.float32, device=film_local.device)
-        dist.all_gather_into_tensor(recv, send)
-    else:
-        recv = send
-    frame = torch.zeros(height * width, 3, dtype=torch.float32, device=film_local.device)
-    recv = recv.reshape(world, n_max, 3)
-    for r in range(world):
-        idx = torch.from_numpy(shard_pixels(width, height, r, world).astype(np.int64)).to(film_local.device)
-        frame[idx] = recv[r, : idx.numel()]
-    return frame
+    """One-shot form of GatherPlan(...).gather(...): film_local [n_owned, 3] in shard_pixels order -> full frame on
+    every rank. With world == 1 (or dist None) it is a local scatter."""
+    return GatherPlan(width, height, world, film_local.device).gather(film_local, dist)
