@@ -183,7 +183,7 @@ def main():
     }
 
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
         cpu = _cpu_baseline(crt, desc, args)
 
     out = {
