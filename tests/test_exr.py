@@ -1,0 +1,42 @@
+"""EXR writer / reader round trips and the reference's exr_diff metrics (examples/exr_diff.rs:45-86)."""
+import struct
+
+import numpy as np
+import pytest
+
+
+@pytest.mark.parametrize("comp", [0, 1, 2, 3])
+def test_round_trip_every_supported_compression(crt, tmp_path, comp):
+    rng = np.random.default_rng(comp)
+    img = rng.random((37, 53, 3), dtype=np.float32) * 4.0
+    img[5:20, 10:40] = 0.25  # flat region: runs for RLE / ZIP
+    img[0, 0] = (np.float32(1e-30), np.float32(65504.0), np.float32(-3.5))
+    p = str(tmp_path / "a.exr")
+    crt.exr.write_exr(p, img, compression=comp)
+    back = crt.exr.read_exr(p)
+    assert back.shape == img.shape and np.array_equal(back.view(np.uint32), img.view(np.uint32))
+
+
+def test_file_layout(crt, tmp_path):
+    p = str(tmp_path / "b.exr")
+    crt.exr.write_exr(p, np.zeros((4, 6, 3), np.float32))
+    raw = open(p, "rb").read()
+    assert struct.unpack_from("<ii", raw, 0) == (20000630, 2)
+    for key in (b"channels\0chlist\0", b"compression\0compression\0", b"dataWindow\0box2i\0", b"displayWindow\0box2i\0",
+                b"lineOrder\0lineOrder\0", b"pixelAspectRatio\0float\0", b"screenWindowCenter\0v2f\0",
+                b"screenWindowWidth\0float\0"):
+        assert key in raw
+    assert raw.index(b"B\0") < raw.index(b"G\0") < raw.index(b"R\0")  # channels sorted by name
+    # 4 scanline blocks of 8 + 6*3*4 bytes after the header and a 4-entry offset table
+    assert len(raw) == raw.index(b"screenWindowWidth") + len(b"screenWindowWidth\0float\0") + 4 + 4 + 1 + 4 * 8 + 4 * (8 + 72)
+
+
+def test_diff_metrics(crt):
+    a = np.ones((2, 3, 3), np.float32)
+    b = a.copy()
+    assert crt.exr.diff(a, b) == dict(differing_pixels=0, total_pixels=6, max_abs=0.0, max_rel=0.0, mean_abs=0.0)
+    b[1, 2, 0] = 1.5
+    b[0, 0, 2] = 0.75
+    r = crt.exr.diff(a, b)
+    assert r["differing_pixels"] == 2 and r["max_abs"] == 0.5
+    assert abs(r["max_rel"] - 0.5 / 1.5) < 1e-7 and abs(r["mean_abs"] - 0.75 / 18) < 1e-9
