@@ -26,6 +26,29 @@ def test_tree_matches_oracle(crt, name):
     assert a.has_motion() == b.has_motion()
 
 
+def _same_tree(a, b):
+    on, ol, op, oi = a.arrays()
+    pn, pl, pp, pi, counts = b.tree()
+    assert counts == a.counts()
+    assert np.array_equal(on[:, :29], pn[:, :29]) and np.array_equal(ol, pl)
+    assert np.array_equal(op[:, :47], pp[:, :47]) and np.array_equal(oi, pi)
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22])
+def test_random_scenes_build_the_same_trees(crt, seed):
+    """Random triangle soups (degenerate, coincident, lattice-aligned), spheres and nested / moving instances: the
+    top-level tree and every prototype tree are identical word for word."""
+    import fuzz_scenes
+    recipe = fuzz_scenes.recipe(seed)
+    a, a_protos = fuzz_scenes.build(ora, recipe)
+    b, b_protos = fuzz_scenes.build(crt, recipe)
+    _same_tree(a, b)
+    for x, y in zip(a_protos, b_protos):
+        _same_tree(x, y)
+    ob, pb = a.bounds(), b.bounds()
+    assert np.array_equal(ob.view(np.uint32), pb.view(np.uint32)) and a.has_motion() == b.has_motion()
+
+
 def test_empty_and_reserved_slots(crt):
     b = crt.SceneBuilder()
     s = b.commit()
