@@ -73,3 +73,82 @@ def build(api, recipe):
     return b.commit(), built
 
 
+
+
+# ---------------------------------------------------------------- random renderable worlds (SceneDesc)
+def _rand_material(rng):
+    """Every OpenPBR knob, with each optional lobe switched on at random (openpbr.rs:66-121)."""
+    u = rng.uniform
+    col = lambda lo=0.05, hi=0.95: tuple(float(x) for x in u(lo, hi, 3))  # noqa: E731
+    m = {"base_weight": float(u(0.3, 1.0)), "base_color": col(), "base_diffuse_roughness": float(u(0, 1)),
+         "specular_weight": float(u(0, 1)), "specular_color": col(0.5, 1.0), "specular_roughness": float(u(0.02, 0.9)),
+         "specular_ior": float(u(1.1, 2.2)), "specular_roughness_anisotropy": float(u(0, 0.9)) if rng.random() < 0.4 else 0.0}
+    if rng.random() < 0.3:
+        m["base_metalness"] = float(u(0.3, 1.0))
+    if rng.random() < 0.35:
+        m.update(transmission_weight=float(u(0.4, 1.0)), transmission_color=col(0.3, 1.0))
+        if rng.random() < 0.6:
+            m["transmission_depth"] = float(u(0.2, 3.0))
+        if rng.random() < 0.4:
+            m.update(transmission_scatter=col(0.0, 0.6), transmission_scatter_anisotropy=float(u(-0.7, 0.7)))
+        if rng.random() < 0.4:
+            m.update(transmission_dispersion_scale=float(u(0.2, 1.0)), transmission_dispersion_abbe_number=float(u(15, 60)))
+        if rng.random() < 0.3:
+            m["thin_walled"] = True
+    if rng.random() < 0.3:
+        m.update(subsurface_weight=float(u(0.3, 1.0)), subsurface_color=col(), subsurface_radius=float(u(0.05, 1.0)),
+                 subsurface_radius_scale=col(0.2, 1.0), subsurface_scatter_anisotropy=float(u(-0.5, 0.8)))
+    if rng.random() < 0.3:
+        m.update(fuzz_weight=float(u(0.2, 1.0)), fuzz_color=col(), fuzz_roughness=float(u(0.1, 0.9)))
+    if rng.random() < 0.35:
+        m.update(coat_weight=float(u(0.2, 1.0)), coat_color=col(0.3, 1.0), coat_roughness=float(u(0.0, 0.5)),
+                 coat_ior=float(u(1.2, 2.0)), coat_darkening=float(u(0, 1)),
+                 coat_roughness_anisotropy=float(u(0, 0.8)) if rng.random() < 0.3 else 0.0)
+    if rng.random() < 0.25:
+        m.update(thin_film_weight=float(u(0.3, 1.0)), thin_film_thickness=float(u(0.1, 1.0)), thin_film_ior=float(u(1.2, 1.8)))
+    if rng.random() < 0.15:
+        m.update(emission_luminance=float(u(0.5, 4.0)), emission_color=col())
+    return m
+
+
+def random_world(usda, seed, width=40, height=28):
+    """A SceneDesc with random OpenPBR materials on spheres, a triangle soup and a ground, one to three lights of both
+    kinds, a random strategy / filter and a random thin-lens camera."""
+    rng = np.random.default_rng(seed)
+    d = usda.SceneDesc()
+    g = np.array([(-8, 0, -8), (8, 0, -8), (8, 0, 8), (-8, 0, 8)], dtype=np.float32)
+    d.geoms.append(dict(kind="mesh", verts=g, idx=np.array([(0, 2, 1), (0, 3, 2)], np.uint32), mask=0xFFFFFFFF,
+                        material=_rand_material(rng), name="ground"))
+    for k in range(int(rng.integers(3, 8))):
+        c = np.array([rng.uniform(-3, 3), rng.uniform(0.4, 2.0), rng.uniform(-3, 3)], dtype=np.float32)
+        d.geoms.append(dict(kind="sphere", center=c, radius=f32(rng.uniform(0.3, 1.0)), mask=0xFFFFFFFF,
+                            material=_rand_material(rng), name="s%d" % k))
+    v, i = _soup(rng, int(rng.integers(10, 60)), 2.5, 0.7)
+    v[:, 1] = np.abs(v[:, 1]) + f32(0.2)
+    d.geoms.append(dict(kind="mesh", verts=v, idx=i, mask=0xFFFFFFFF, material=_rand_material(rng), name="soup"))
+    for k in range(int(rng.integers(1, 4))):
+        rad = tuple(float(x) for x in rng.uniform(2, 30, 3))
+        gid = len(d.geoms)
+        if rng.random() < 0.6:
+            c = np.array([rng.uniform(-4, 4), rng.uniform(3, 6), rng.uniform(-4, 4)], dtype=np.float32)
+            r = f32(rng.uniform(0.1, 0.8))
+            d.geoms.append(dict(kind="sphere", center=c, radius=r, mask=0xFFFFFFFF & ~2,
+                                material={"_preset": "emissive", "emission_color": rad}, name="L%d" % k))
+            d.lights.append(dict(kind="sphere", geom_id=gid, radiance=np.array(rad, np.float32), center=c, radius=r))
+        else:
+            o = np.array([rng.uniform(-3, 1), rng.uniform(4, 6), rng.uniform(-3, 1)], dtype=np.float32)
+            eu = np.array([rng.uniform(0.5, 2), 0, 0], dtype=np.float32)
+            ev = np.array([0, 0, rng.uniform(0.5, 2)], dtype=np.float32)
+            verts = np.stack([o, o + eu, o + eu + ev, o + ev]).astype(np.float32)
+            d.geoms.append(dict(kind="mesh", verts=verts, idx=np.array([(0, 1, 2), (0, 2, 3)], np.uint32), mask=0xFFFFFFFF & ~2,
+                                material={"_preset": "emissive", "emission_color": rad}, name="L%d" % k))
+            d.lights.append(dict(kind="rect", geom_id=gid, radiance=np.array(rad, np.float32), origin=o, edge_u=eu, edge_v=ev,
+                                 normal=np.array([0, -1, 0], np.float32)))
+    lookfrom = np.array([rng.uniform(-2, 2), rng.uniform(1.5, 4), rng.uniform(6, 9)], dtype=np.float32)
+    d.camera = dict(lookfrom=lookfrom, lookat=np.array([0, 1, 0], np.float32), vup=np.array([0, 1, 0], np.float32),
+                    vfov_deg=f32(rng.uniform(30, 70)), aspect=f32(f32(width) / f32(height)),
+                    aperture=f32(rng.uniform(0, 0.3)) if rng.random() < 0.5 else f32(0.0), focus_dist=f32(rng.uniform(5, 9)))
+    d.settings = dict(usda.DEFAULTS, strategy=["power", "balance", "light", "bsdf"][int(rng.integers(0, 4))],
+                      filter=["triangle", "box"][int(rng.integers(0, 2))], filter_radius=float(rng.uniform(0.5, 1.5)),
+                      width=width, height=height, max_depth=int(rng.integers(3, 10)), frame=int(rng.integers(0, 5)))
+    return d
