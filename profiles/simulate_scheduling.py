@@ -98,7 +98,7 @@ def sim_A(all_steps, refill=32):
     return instr, useful
 
 
-def sim_affine(all_tr, rows=2, rare_min=16, overhead=20, fetch_min=32):
+def sim_affine(all_tr, rows=2, rare_min=16, overhead=20, fetch_min=32, chain_min=0):
     """State in LDS but slot r is only ever processed by lane r % 64 (conflict-free LDS, no gather list): a lane
     runs the chosen phase for at most one of its `rows` slots per step."""
     instr = useful = 0
@@ -131,6 +131,7 @@ def sim_affine(all_tr, rows=2, rare_min=16, overhead=20, fetch_min=32):
         cand = rare or common or cnt
         ph = max(cand.items(), key=lambda kv: kv[1])[0]
         k_run = 0
+        ran = []
         for l in range(64):
             for k in range(rows):
                 r = slots[l][k]
@@ -139,9 +140,27 @@ def sim_affine(all_tr, rows=2, rare_min=16, overhead=20, fetch_min=32):
                         slots[l][k] = None
                     else:
                         r[1] += 1
+                        ran.append(r)
                     k_run += 1
                     break
         instr += COST[ph] + overhead; useful += COST[ph] * k_run
+        # chaining: while enough of the rays that just ran agree on their next common phase, run it at once
+        # (state stays in registers: no scheduling round, no LDS round trip)
+        while chain_min and ran:
+            follow = {}
+            for r in ran:
+                p2 = ph_of(r)
+                if p2 in "NP":
+                    follow.setdefault(p2, []).append(r)
+            if not follow:
+                break
+            p2, rs = max(follow.items(), key=lambda kv: len(kv[1]))
+            if len(rs) < chain_min:
+                break
+            for r in rs:
+                r[1] += 1
+            instr += COST[p2] + 10; useful += COST[p2] * len(rs)
+            ran = rs
     return instr, useful
 
 
@@ -233,6 +252,11 @@ def main():
             ("D lane-affine 2 rows", sim_affine(tr, rows=2)),
             ("D lane-affine 3 rows", sim_affine(tr, rows=3)),
             ("D lane-affine 4 rows", sim_affine(tr, rows=4)),
+            ("D 2 rows, overhead 90", sim_affine(tr, rows=2, overhead=90)),
+            ("D 2 rows, ovh 90, chain>=24", sim_affine(tr, rows=2, overhead=90, chain_min=24)),
+            ("D 2 rows, ovh 90, chain>=32", sim_affine(tr, rows=2, overhead=90, chain_min=32)),
+            ("D 2 rows, ovh 90, chain>=16", sim_affine(tr, rows=2, overhead=90, chain_min=16)),
+            ("D 2 rows, ovh 90, chain>=40", sim_affine(tr, rows=2, overhead=90, chain_min=40)),
         ):
             print(f"   {name:28s} wave-instr/ray {ins / len(tr):7.2f}   lane utilisation {use / (64.0 * ins):5.3f}")
 
