@@ -135,7 +135,7 @@ class CrtCamera(C.Structure):
 class CrtRenderSettings(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("max_depth", C.c_uint32), ("frame", C.c_int32),
                 ("strategy", C.c_int32), ("filter_kind", C.c_int32), ("filter_radius", C.c_float),
-                ("variance_threshold", C.c_float)]
+                ("variance_threshold", C.c_float), ("min_spp", C.c_uint32)]
 
 
 class CrtRayStats(C.Structure):
@@ -158,7 +158,7 @@ ABI_SYMBOLS = [
     "crt_shard_pixels", "crt_intersect1", "crt_occluded1", "crt_intersect_n", "crt_occluded_n", "crt_intersect_n_stats",
     "crt_occluded_n_stats", "crt_material_default", "crt_camera_new", "crt_renderer_new", "crt_renderer_free",
     "crt_renderer_pixel_count", "crt_renderer_pixel_indices", "crt_render_samples", "crt_film_resolve",
-    "crt_film_read", "crt_film_clear", "crt_render_stats", "crt_renderer_profile", "crt_renderer_profile_read",
+    "crt_film_read", "crt_film_clear", "crt_renderer_active_pixels", "crt_renderer_sample_counts", "crt_render_stats", "crt_renderer_profile", "crt_renderer_profile_read",
     "crt_render_samples_stats", "crt_version", "crt_last_error", "crt_device_info",
 ]
 
@@ -230,6 +230,9 @@ def lib():
         L.crt_film_read.argtypes = [vp, fp]
         L.crt_film_clear.argtypes = [vp, vp]
         L.crt_render_stats.argtypes = [vp, C.POINTER(CrtRayStats)]
+        L.crt_renderer_active_pixels.restype = C.c_size_t
+        L.crt_renderer_active_pixels.argtypes = [vp]
+        L.crt_renderer_sample_counts.argtypes = [vp, up]
         L.crt_renderer_profile.argtypes = [vp, C.c_int]
         L.crt_renderer_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         L.crt_render_samples_stats.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.POINTER(CrtTravStats)]
@@ -510,15 +513,17 @@ class RenderSettings:
     """crust_core::RenderSettings (tracer.rs:640-735) for the wavefront path."""
 
     def __init__(self, width, height, max_depth=32, frame=0, strategy="power", pixel_filter="triangle",
-                 filter_radius=None, variance_threshold=0.0):
+                 filter_radius=None, variance_threshold=0.0, min_spp=32):
         self.width, self.height, self.max_depth, self.frame = int(width), int(height), int(max_depth), int(frame)
         self.strategy, self.pixel_filter = strategy, pixel_filter
         self.filter_radius = filter_radius if filter_radius is not None else (0.5 if pixel_filter == "box" else 1.0)
-        self.variance_threshold = variance_threshold
+        self.variance_threshold = variance_threshold  # > 0: render_pixel's adaptive early stop (tracer.rs:609-617)
+        self.min_spp = int(min_spp)
 
     def c(self):
         return CrtRenderSettings(self.width, self.height, self.max_depth, self.frame, STRATEGY[self.strategy],
-                                 FILTER[self.pixel_filter], float(self.filter_radius), float(self.variance_threshold))
+                                 FILTER[self.pixel_filter], float(self.filter_radius), float(self.variance_threshold),
+                                 self.min_spp)
 
 
 def make_camera(lookfrom, lookat, vup, vfov_deg, aspect, aperture, focus_dist):
@@ -608,6 +613,28 @@ class Renderer:
         _check(lib().crt_render_stats(self.h, C.byref(s)), "crt_render_stats")
         return s
 
+    def active_pixels(self):
+        """Adaptive stopping: owned pixels still sampling."""
+        return int(lib().crt_renderer_active_pixels(self.h))
+
+    def sample_counts(self):
+        """Adaptive stopping: samples taken per owned pixel (pixel_indices order)."""
+        out = np.zeros(self.n_pix, dtype=np.uint32)
+        _check(lib().crt_renderer_sample_counts(self.h, out.ctypes.data_as(C.POINTER(C.c_uint32))), "crt_renderer_sample_counts")
+        return out
+
+    def render_adaptive(self, spp, first=None, batch=4, stream=None):
+        """Renderer::render_pass with adaptive stopping (tracer.rs:515-636): `first` samples (default min_spp rounded
+        up to a multiple of 4) for every pixel, then batches of `batch` for the pixels still sampling, up to `spp`.
+        With batch == 4 the ray counters equal the reference's: the rule can only fire on multiples of 4."""
+        first = first or -(-max(self.settings.min_spp, 2) // 4) * 4
+        s = 0
+        while s < spp and self.active_pixels() > 0:
+            n = min(first if s == 0 else batch, spp - s)
+            self.render_samples(s, n, stream)
+            s += n
+        return s
+
     def profile(self, enable=True):
         _check(lib().crt_renderer_profile(self.h, 1 if enable else 0), "crt_renderer_profile")
 
@@ -619,9 +646,11 @@ class Renderer:
         return {names[k]: dict(ms=float(ms[k]), launches=int(n[k])) for k in range(4)}
 
 
-def load_usda(path, width=None, height=None, max_depth=None, rank=0, world=1):
+def load_usda(path, width=None, height=None, max_depth=None, rank=0, world=1, variance=0.0, min_spp=None):
     """Scene::from_usd (scene.rs / usd_import.rs:287-424) for the text sample scenes -> (Renderer, desc).
-    `path` may also name a synthetic scene: "synthetic:city" or "synthetic:city:<side>" (synthetic.py)."""
+    `path` may also name a synthetic scene: "synthetic:city" or "synthetic:city:<side>" (synthetic.py).
+    variance > 0 enables adaptive stopping (the scene files' own default is 0.05; 0 = every sample, the rule for
+    comparable runs, scripts/check_images.sh:5-11)."""
     from . import usda
     import sys
     if str(path).startswith("synthetic:"):
@@ -635,7 +664,8 @@ def load_usda(path, width=None, height=None, max_depth=None, rank=0, world=1):
     scene, materials, protos = usda.build_world(desc, me, default_material)
     s = desc.settings
     settings = RenderSettings(s["width"], s["height"], s["max_depth"] if max_depth is None else max_depth, s["frame"],
-                              s["strategy"], s["filter"], s["filter_radius"], 0.0)
+                              s["strategy"], s["filter"], s["filter_radius"], float(variance),
+                              s["min_spp"] if min_spp is None else min_spp)
     cam = make_camera(**desc.camera)
     r = Renderer(scene, materials, desc.lights, cam, settings, rank, world)
     r._protos = protos

@@ -138,6 +138,10 @@ struct Params {
   uint32_t has_motion;
   const uint32_t *pixel_index;  // owned pixels: j * width + i
   uint32_t n_pix;
+  // Adaptive stopping (tracer.rs:609-617): the pixels still sampling. active == nullptr: all n_pix, in order.
+  // A path carries its ACTIVE slot; the staging film is indexed [sample][active slot].
+  const uint32_t *active;
+  uint32_t n_act;
   uint32_t seg_cap;             // slots per workgroup segment
 };
 
@@ -219,7 +223,7 @@ __device__ __forceinline__ void generate_segment(const Params &P, const PathSoA 
   // segment b holds global sample g = ((k / 256) * G + b) * 256 + k % 256. Every segment is then a uniform
   // sample of the frame (sky and geometry alike), so the per-segment work stays balanced at every bounce, while
   // a wave still holds 64 consecutive pixels of one 16x16 tile (coherent primary rays).
-  const size_t total = (size_t)P.n_pix * n_samples;
+  const size_t total = (size_t)P.n_act * n_samples;
   const size_t seg0 = (size_t)blockIdx.x * kBins * P.seg_cap;  // camera rays are coherent as dealt: all in bin 0
   const size_t G = gridDim.x;
   uint32_t seg_n = 0;
@@ -228,8 +232,8 @@ __device__ __forceinline__ void generate_segment(const Params &P, const PathSoA 
     if (g >= total) break;
     seg_n = (uint32_t)k + 1;
     const size_t i = seg0 + k;
-    const uint32_t pix = (uint32_t)(g % P.n_pix), sl = (uint32_t)(g / P.n_pix);
-    const uint32_t lin = P.pixel_index[pix];
+    const uint32_t pix = (uint32_t)(g % P.n_act), sl = (uint32_t)(g / P.n_act);  // pix: active slot
+    const uint32_t lin = P.pixel_index[P.active ? P.active[pix] : pix];
     const uint32_t px = lin % P.width, py = lin / P.width;
     const int tile = (int)(px >> 8) + (int)(py >> 8) * 4096;  // tracer.rs:543
     const Sampler root = new_domain(sampler_new((int)px, (int)py, P.frame, (int)(sample_begin + sl)), tile);
@@ -378,7 +382,7 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
           const float t = 0.5f * (unit_direction.y + 1.0f);
           const V3 background = splat(0.0f) + (v3(1.0f, 1.0f, 1.0f) * (1.0f - t) + v3(0.5f, 0.7f, 1.0f) * t);
           L = L + beta * background;
-          staging[(D.w & 0xffffu) * P.n_pix + D.y] = make_float4(L.x, L.y, L.z, 0.0f);
+          staging[(D.w & 0xffffu) * P.n_act + D.y] = make_float4(L.x, L.y, L.z, 0.0f);
         } else {
           pending = true;
         }
@@ -587,7 +591,7 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
       }
     }
     const uint32_t sl = aux & 0xffffu;
-    const uint32_t film_idx = sl * P.n_pix + pix;
+    const uint32_t film_idx = sl * P.n_act + pix;
     if (alive) {
       N.a[j] = make_float4(n_o.x, n_o.y, n_o.z, n_d.x);
       N.b[j] = make_float4(n_d.y, n_d.z, beta.x, beta.y);
@@ -724,6 +728,61 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const float4 *staging, uint3
   }
 }
 
+// ---- adaptive variant (tracer.rs:599-617): the same fold, plus the luminance statistics in f64 and the stopping
+// rule evaluated after every 4th sample once min_spp are in — exactly where render_pixel evaluates it. A pixel that
+// stops ignores the rest of the batch (those samples were traced but are not part of its estimate). ----
+struct PixelStats { double lum_sum, lum_sq; };
+__global__ __launch_bounds__(kBlock) void k_resolve_adaptive(const float4 *staging, const uint32_t *active, uint32_t n_act,
+                                                             uint32_t n_samples, float4 *film, PixelStats *stats,
+                                                             uint32_t *state /* taken | stopped << 31 */,
+                                                             uint32_t min_spp, float variance_threshold) {
+  const double threshold = (double)variance_threshold;
+  for (uint32_t a = blockIdx.x * kBlock + threadIdx.x; a < n_act; a += gridDim.x * kBlock) {
+    const uint32_t p = active ? active[a] : a;
+    float4 acc = film[p];
+    PixelStats ps = stats[p];
+    uint32_t st = state[p];
+    uint32_t taken = st & 0x7fffffffu;
+    bool stopped = (st >> 31) != 0;
+    for (uint32_t s = 0; s < n_samples && !stopped; s++) {
+      const float4 v = staging[(size_t)s * n_act + a];
+      acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z;
+      acc.w = acc.w + 1.0f;
+      const double lum = (double)(0.2126f * v.x + 0.7152f * v.y + 0.0722f * v.z);  // guiding/mod.rs:18-20
+      ps.lum_sum += lum;
+      ps.lum_sq += lum * lum;
+      taken++;
+      if (threshold > 0.0 && taken >= min_spp && taken % 4 == 0) {
+        const double n = (double)taken;
+        double var_of_mean = (ps.lum_sq - ps.lum_sum * ps.lum_sum / n) / (n - 1.0) / n;
+        if (!(var_of_mean > 0.0)) var_of_mean = 0.0;
+        double mean = ps.lum_sum / n;
+        if (!(mean > 1e-4)) mean = 1e-4;
+        if (sqrt(var_of_mean) / mean < threshold) stopped = true;
+      }
+    }
+    film[p] = acc;
+    stats[p] = ps;
+    state[p] = taken | (stopped ? 0x80000000u : 0u);
+  }
+}
+// The pixels still sampling, as a list of owned-pixel indices (order irrelevant: every pixel is independent).
+__global__ __launch_bounds__(kBlock) void k_compact_active(const uint32_t *state, uint32_t n_pix, uint32_t *active,
+                                                           uint32_t *count) {
+  for (uint32_t base = blockIdx.x * kBlock; base < n_pix; base += gridDim.x * kBlock) {
+    const uint32_t p = base + threadIdx.x;
+    const bool on = p < n_pix && (state[p] >> 31) == 0;
+    const unsigned long long m = __ballot(on);
+    if (m == 0) continue;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t at = 0;
+    if (lane == leader) at = atomicAdd(count, (uint32_t)__popcll(m));
+    at = __shfl(at, leader, 64) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (on) active[at] = p;
+  }
+}
+
 // pixel = sum / weight_sum (tracer.rs:630-634); rgb interleaved per owned pixel.
 __global__ __launch_bounds__(kBlock) void k_film_out(const float4 *film, uint32_t n_pix, float *rgb) {
   for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < n_pix; p += gridDim.x * kBlock) {
@@ -754,6 +813,11 @@ struct Renderer {
   CrtMaterial *d_materials = nullptr;
   DevMedium *d_media = nullptr;  // [n_materials] by geom_id, then [n_materials] by compact id
   bool has_media = false;
+  // adaptive stopping (variance_threshold > 0): per-pixel luminance statistics, sample counts and the active list
+  PixelStats *d_pstats = nullptr;
+  uint32_t *d_state = nullptr, *d_active = nullptr, *d_count = nullptr;
+  uint32_t n_act = 0, min_spp = 2;
+  float variance_threshold = 0.0f;
   bool fused = true;  // CRT_FUSED=0: one launch per stage and bounce (per-stage timing, A/B)
   CrtLight *d_lights = nullptr;
   uint32_t *d_pixels = nullptr;
@@ -772,6 +836,10 @@ struct Renderer {
     if (film) (void)hipFree(film);
     if (d_materials) (void)hipFree(d_materials);
     if (d_media) (void)hipFree(d_media);
+    if (d_pstats) (void)hipFree(d_pstats);
+    if (d_state) (void)hipFree(d_state);
+    if (d_active) (void)hipFree(d_active);
+    if (d_count) (void)hipFree(d_count);
     if (d_lights) (void)hipFree(d_lights);
     if (d_pixels) (void)hipFree(d_pixels);
   }
@@ -836,12 +904,34 @@ struct Renderer {
     int rc = ensure_buffers(n_samples);
     if (rc != CRT_OK) return rc;
     last_stream = st;
+    const bool adaptive = variance_threshold > 0.0f;
+    if (adaptive && n_act == 0) return CRT_OK;  // every pixel has stopped
     Params p = P;
     p.sample_begin = sample_begin;
-    {  // segment size for THIS batch size (buffers may be larger)
-      const size_t total = (size_t)P.n_pix * n_samples;
+    p.n_act = adaptive ? n_act : P.n_pix;
+    p.active = (adaptive && n_act < P.n_pix) ? d_active : nullptr;
+    {  // segment size for THIS batch (buffers may be larger)
+      const size_t total = (size_t)p.n_act * n_samples;
       p.seg_cap = (uint32_t)(((total + (size_t)grid * kBlock - 1) / ((size_t)grid * kBlock)) * kBlock);
     }
+    // the film fold: plain sum, or with the luminance statistics and the stopping rule, then the new active list
+    auto fold = [&]() -> int {
+      if (!adaptive) {
+        timed(3, st, [&] { hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(kBlock), 0, st, staging, P.n_pix, n_samples, film); });
+        return CRT_HIP_OK(hipGetLastError()) ? CRT_OK : CRT_ERR_NO_DEVICE;
+      }
+      timed(3, st, [&] {
+        hipLaunchKernelGGL(k_resolve_adaptive, dim3(grid), dim3(kBlock), 0, st, staging, p.active, p.n_act, n_samples, film,
+                           d_pstats, d_state, min_spp, variance_threshold);
+        (void)hipMemsetAsync(d_count, 0, 4, st);
+        hipLaunchKernelGGL(k_compact_active, dim3(grid), dim3(kBlock), 0, st, d_state, P.n_pix, d_active, d_count);
+      });
+      uint32_t h = 0;  // the next batch's size is a launch parameter: one 4-byte read-back per batch
+      if (!CRT_HIP_OK(hipMemcpyAsync(&h, d_count, 4, hipMemcpyDeviceToHost, st)) || !CRT_HIP_OK(hipStreamSynchronize(st)))
+        return CRT_ERR_NO_DEVICE;
+      n_act = h;
+      return CRT_OK;
+    };
     const bool lit = P.n_lights > 0 && P.strategy != CRT_STRATEGY_BSDF;
     if (fused && !d_tstats) {  // one launch for the whole path loop (class 0 of the profile), then the film fold
       timed(0, st, [&] {
@@ -853,8 +943,7 @@ struct Renderer {
           else hipLaunchKernelGGL((k_path<false, false>), dim3(grid), dim3(kBlock), 0, st, p, S[0], S[1], H, Q, C, staging, sample_begin, n_samples);
         }
       });
-      timed(3, st, [&] { hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(kBlock), 0, st, staging, P.n_pix, n_samples, film); });
-      return CRT_HIP_OK(hipGetLastError()) ? CRT_OK : CRT_ERR_NO_DEVICE;
+      return fold();
     }
     timed(3, st, [&] { hipLaunchKernelGGL(k_generate, dim3(grid), dim3(kBlock), 0, st, p, S[0], C, sample_begin, n_samples); });
     int cur = 0;
@@ -869,8 +958,7 @@ struct Renderer {
       }
       cur = 1 - cur;
     }
-    timed(3, st, [&] { hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(kBlock), 0, st, staging, P.n_pix, n_samples, film); });
-    return CRT_HIP_OK(hipGetLastError()) ? CRT_OK : CRT_ERR_NO_DEVICE;
+    return fold();
   }
 };
 
@@ -917,7 +1005,7 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
                               uint32_t tile_rank, uint32_t tile_world) {
   if (!scene || !camera || !settings || (n_materials && !materials) || (n_lights && !lights)) return nullptr;
   if (tile_world == 0 || tile_rank >= tile_world) return nullptr;
-  if (settings->variance_threshold != 0.0f) return nullptr;  // adaptive stopping is a per-pixel host loop: not here
+  if (!(settings->variance_threshold >= 0.0f)) return nullptr;
   if (n_materials < scene->p->n_geoms) return nullptr;        // one material per geom_id (rt_world.rs:111-122)
   if (settings->max_depth > 0xffffu) return nullptr;
   if (scene->p->ensure_device() != CRT_OK) return nullptr;
@@ -937,7 +1025,17 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
   r.pixels.resize(crt_shard_pixels(P.width, P.height, tile_rank, tile_world, nullptr));
   crt_shard_pixels(P.width, P.height, tile_rank, tile_world, r.pixels.data());
   P.n_pix = (uint32_t)r.pixels.size();
+  P.n_act = P.n_pix; P.active = nullptr;
+  r.variance_threshold = settings->variance_threshold;
+  r.min_spp = settings->min_spp > 2 ? settings->min_spp : 2;  // tracer.rs:526
+  r.n_act = P.n_pix;
   bool ok = P.n_pix > 0;
+  if (ok && r.variance_threshold > 0.0f) {
+    ok = CRT_HIP_OK(hipMalloc(&r.d_pstats, (size_t)P.n_pix * sizeof(PixelStats))) &&
+         CRT_HIP_OK(hipMemset(r.d_pstats, 0, (size_t)P.n_pix * sizeof(PixelStats))) &&
+         CRT_HIP_OK(hipMalloc(&r.d_state, (size_t)P.n_pix * 4)) && CRT_HIP_OK(hipMemset(r.d_state, 0, (size_t)P.n_pix * 4)) &&
+         CRT_HIP_OK(hipMalloc(&r.d_active, (size_t)P.n_pix * 4)) && CRT_HIP_OK(hipMalloc(&r.d_count, 4));
+  }
   ok = ok && CRT_HIP_OK(hipMalloc(&r.C, sizeof(Counters))) && CRT_HIP_OK(hipMemset(r.C, 0, sizeof(Counters)));
   ok = ok && CRT_HIP_OK(hipMalloc(&r.film, (size_t)P.n_pix * 16)) && CRT_HIP_OK(hipMemset(r.film, 0, (size_t)P.n_pix * 16));
   ok = ok && CRT_HIP_OK(hipMalloc(&r.d_pixels, (size_t)P.n_pix * 4)) &&
@@ -1033,6 +1131,11 @@ int crt_film_clear(CrtRenderer *r, void *stream) {
   if (!r) return CRT_ERR_BAD_ARG;
   bool ok = CRT_HIP_OK(hipMemsetAsync(r->r.film, 0, (size_t)r->r.P.n_pix * 16, (hipStream_t)stream));
   ok = ok && CRT_HIP_OK(hipMemsetAsync(r->r.C, 0, sizeof(Counters), (hipStream_t)stream));
+  if (ok && r->r.d_state) {
+    ok = CRT_HIP_OK(hipMemsetAsync(r->r.d_state, 0, (size_t)r->r.P.n_pix * 4, (hipStream_t)stream)) &&
+         CRT_HIP_OK(hipMemsetAsync(r->r.d_pstats, 0, (size_t)r->r.P.n_pix * sizeof(PixelStats), (hipStream_t)stream));
+    r->r.n_act = r->r.P.n_pix;
+  }
   return ok ? CRT_OK : CRT_ERR_NO_DEVICE;
 }
 int crt_render_stats(CrtRenderer *r, CrtRayStats *out) {
@@ -1045,6 +1148,15 @@ int crt_render_stats(CrtRenderer *r, CrtRayStats *out) {
   out->vertices = h.stats[3]; out->rr_tested = h.stats[4]; out->rr_killed = h.stats[5];
   out->ended_escaped = h.stats[6]; out->ended_depth = h.stats[7];
   return h.err ? CRT_ERR_STACK : CRT_OK;
+}
+size_t crt_renderer_active_pixels(const CrtRenderer *r) { return r ? (r->r.variance_threshold > 0.0f ? r->r.n_act : r->r.P.n_pix) : 0; }
+int crt_renderer_sample_counts(CrtRenderer *r, uint32_t *host_out) {
+  if (!r || !host_out) return CRT_ERR_BAD_ARG;
+  if (!r->r.d_state) return CRT_ERR_UNSUPPORTED;
+  if (!CRT_HIP_OK(hipStreamSynchronize(r->r.last_stream))) return CRT_ERR_NO_DEVICE;
+  if (!CRT_HIP_OK(hipMemcpy(host_out, r->r.d_state, (size_t)r->r.P.n_pix * 4, hipMemcpyDeviceToHost))) return CRT_ERR_NO_DEVICE;
+  for (size_t k = 0; k < r->r.P.n_pix; k++) host_out[k] &= 0x7fffffffu;
+  return CRT_OK;
 }
 int crt_renderer_profile(CrtRenderer *r, int enable) {
   if (!r) return CRT_ERR_BAD_ARG;

@@ -185,9 +185,12 @@ void crt_camera_new(CrtCamera *c, const float lookfrom[3], const float lookat[3]
 enum { CRT_STRATEGY_POWER = 0, CRT_STRATEGY_BALANCE = 1, CRT_STRATEGY_LIGHT = 2, CRT_STRATEGY_BSDF = 3 }; /* tracer.rs:63-75 */
 enum { CRT_FILTER_BOX = 0, CRT_FILTER_TRIANGLE = 1 };                                                       /* filter.rs:27-41 */
 
-/* RenderSettings (tracer.rs:640-686) for the surface path. Adaptive stopping is not available on the
- * wavefront path: variance_threshold must be 0 (the reference's own rule for comparable runs,
- * scripts/check_images.sh:5-11). */
+/* RenderSettings (tracer.rs:640-686). variance_threshold > 0 turns on render_pixel's adaptive early stop
+ * (tracer.rs:609-617): per pixel, after every 4th sample once min_spp samples are in, stop when the relative
+ * standard error of the mean luminance falls below the threshold. The rule is evaluated sample by sample inside
+ * the film fold, so the image does not depend on how the samples are batched; a pixel that stops inside a batch
+ * has had the rest of that batch traced in vain (RayStats then counts those rays: use batches of 4 samples after
+ * the first min_spp to count exactly what the reference counts). 0 = every pixel takes every sample. */
 typedef struct CrtRenderSettings {
   uint32_t width, height;
   uint32_t max_depth;
@@ -196,6 +199,7 @@ typedef struct CrtRenderSettings {
   int32_t filter_kind;
   float filter_radius;
   float variance_threshold;
+  uint32_t min_spp;          /* RenderSettings::min_samples; values below 2 mean 2 (tracer.rs:526) */
 } CrtRenderSettings;
 
 /* RayStats (stats.rs:128-147). */
@@ -222,13 +226,18 @@ size_t crt_renderer_pixel_count(const CrtRenderer *r);
 int crt_renderer_pixel_indices(const CrtRenderer *r, uint32_t *out);
 /* Traces samples [sample_begin, sample_begin + sample_count) of every owned pixel as one wavefront batch
  * on `stream` and adds them, in sample order, into the renderer's device-resident film sums
- * (render_pixel's `sum += color`, tracer.rs:599). Does not synchronise. */
+ * (render_pixel's `sum += color`, tracer.rs:599). Does not synchronise — except with adaptive stopping, where the
+ * size of the next batch (the pixels still sampling) is read back after the fold. */
 int crt_render_samples(CrtRenderer *r, uint32_t sample_begin, uint32_t sample_count, void *stream);
 /* Film: pixel = sum / weight_sum (tracer.rs:630-634) for the owned pixels, in pixel_indices order,
  * written to a DEVICE buffer of pixel_count*3 floats (d_rgb), or a HOST buffer via crt_film_read. */
 int crt_film_resolve(CrtRenderer *r, float *d_rgb, void *stream);
 int crt_film_read(CrtRenderer *r, float *host_rgb);
 int crt_film_clear(CrtRenderer *r, void *stream);
+/* Adaptive stopping: how many owned pixels are still sampling (all of them when variance_threshold == 0), and
+ * the samples each owned pixel has taken so far (pixel_indices order; CRT_ERR_UNSUPPORTED without adaptive stopping). */
+size_t crt_renderer_active_pixels(const CrtRenderer *r);
+int crt_renderer_sample_counts(CrtRenderer *r, uint32_t *host_out);
 /* Counters since the last clear (syncs the stream the batches ran on). */
 int crt_render_stats(CrtRenderer *r, CrtRayStats *out);
 /* Live HIP-event timing of the kernels launched by crt_render_samples since the last reset, by class:

@@ -27,7 +27,7 @@ def make_lights(light_dicts):
 
 
 class OracleRenderer:
-    def __init__(self, desc, usda_mod, width=None, height=None, max_depth=None, forward=1):
+    def __init__(self, desc, usda_mod, width=None, height=None, max_depth=None, forward=1, variance=0.0, min_spp=None):
         self.desc = desc
         self.scene, mats, self._protos = usda_mod.build_world(desc, ora, ora.default_material)
         self._mats = (ora.Material * max(len(mats), 1))(*mats)
@@ -48,8 +48,8 @@ class OracleRenderer:
         j.width, j.height = s["width"], s["height"]
         j.spp = s["spp"]
         j.max_depth = s["max_depth"] if max_depth is None else max_depth
-        j.min_spp = s["min_spp"]
-        j.variance_threshold = 0.0
+        j.min_spp = s["min_spp"] if min_spp is None else min_spp
+        j.variance_threshold = float(variance)
         j.frame = s["frame"]
         j.strategy = STRATEGY[s["strategy"]]
         j.filter_kind = FILTER[s["filter"]]

@@ -59,6 +59,33 @@ def test_synthetic_city_identical_to_oracle(crt):
     assert st.shadow_rays > 0 and np.array_equal(img.view(np.uint32), oimg.view(np.uint32))
 
 
+def test_adaptive_stopping_identical_to_oracle(crt):
+    """render_pixel's adaptive early stop (tracer.rs:609-617): same image, and — with batches of 4 samples after
+    the first min_spp, where the rule can fire — the same ray counters and per-pixel sample counts."""
+    import torch
+    path = os.path.join(ROOT, "scenes", "veach_mis.usda")
+    w, h, spp, min_spp, var = 64, 36, 48, 8, 0.08
+    r, desc = crt.load_usda(path, w, h, 8, variance=var, min_spp=min_spp)
+    done = r.render_adaptive(spp)
+    torch.cuda.synchronize()
+    img, st = r.image(), r.stats()
+    o = ora_world.OracleRenderer(desc, crt.usda, max_depth=8, variance=var, min_spp=min_spp)
+    oimg, ost = o.render(spp, forward=1)
+    counts = r.sample_counts()
+    assert 0 < (counts < spp).sum() < counts.size, "the threshold should stop some pixels early and not others"
+    assert (counts % 4 == 0).all() and counts.min() >= min_spp and done <= spp
+    assert st.camera_rays == int(counts.sum()) == ost.camera_rays
+    for f, _t in ora.RayStats._fields_:
+        assert getattr(st, f) == getattr(ost, f), f
+    assert np.array_equal(img.view(np.uint32), oimg.view(np.uint32))
+    # any other batching gives the same image (the rule is evaluated per sample inside the fold)
+    r2, _ = crt.load_usda(path, w, h, 8, variance=var, min_spp=min_spp)
+    r2.render_adaptive(spp, first=20, batch=28)
+    torch.cuda.synchronize()
+    assert np.array_equal(r2.image().view(np.uint32), oimg.view(np.uint32))
+    assert np.array_equal(r2.sample_counts(), counts)
+
+
 def test_batches_accumulate_in_sample_order(crt):
     """Rendering 8 spp as 1 batch or as 4 batches of 2 must give the same bits (sum += color in sample order)."""
     a, *_ = _both(crt, "veach_mis", 64, 36, 8, 8, batch=8)
