@@ -84,6 +84,8 @@ def main():
     crt.lib()
     # a sample scene file, or a labelled synthetic scene ("synthetic:city[:side]", crust-render_amd/synthetic.py)
     path = args.scene if args.scene.startswith("synthetic:") else os.path.join(ROOT, "scenes", args.scene + ".usda")
+    if not args.scene.startswith("synthetic:") and not os.path.exists(path):
+        path = os.path.join(ROOT, "scenes", args.scene + ".usd")  # binary crate (PointInstancedMedCity)
     r, desc = crt.load_usda(path, args.width, args.height, args.depth, rank=rank, world=world)
     spp_step = args.spp_per_step * world
     stream = torch.cuda.current_stream()
@@ -200,10 +202,10 @@ def main():
         "dtype": "f32",
         "data": ("synthetic scene %s (generated in code, NOT a reference file), seeded sampler, frame 0" % args.scene)
                 if args.scene.startswith("synthetic:") else
-                ("the reference's own sample scene file (scenes/%s.usda), seeded sampler, frame 0" % args.scene),
+                ("the reference's own sample scene file (scenes/%s), seeded sampler, frame 0" % os.path.basename(path)),
         "config": {
             "workload": "%s %dx%d, %d spp per step per GPU-share (x%d GPUs), depth %d, triangle r=1, "
-                        "variance 0; %d steps = %d spp" % (args.scene if args.scene.startswith("synthetic:") else "samples/%s.usda" % args.scene, args.width, args.height, args.spp_per_step, world,
+                        "variance 0; %d steps = %d spp" % (args.scene if args.scene.startswith("synthetic:") else "samples/" + os.path.basename(path), args.width, args.height, args.spp_per_step, world,
                                                            r.settings.max_depth, args.steps, args.steps * spp_step),
             "spp_per_step": spp_step,
             "paths_per_step_per_gpu": r.n_pix * spp_step,

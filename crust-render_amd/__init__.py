@@ -672,6 +672,7 @@ def load_usda(path, width=None, height=None, max_depth=None, rank=0, world=1, va
     return r, desc
 
 from . import usda  # noqa: E402,F401  (the minimal USDA reader)
+from . import usdc  # noqa: E402,F401  (the USDC crate reader)
 from . import shard  # noqa: E402,F401  (pixel-tile sharding + the tile gather)
 from . import exr  # noqa: E402,F401  (EXR writer / reader + the reference's exr_diff metrics)
 from . import synthetic  # noqa: E402,F401  (scenes built in code: the labelled stand-in for BASELINE config 5)

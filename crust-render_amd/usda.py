@@ -285,6 +285,24 @@ def local_matrix(prim):  # compose_xform_ops, usd_import.rs:574-602
     return local
 
 
+def _from_scale_rotation_translation(scale, q_xyzw, t):
+    """glam Mat4::from_scale_rotation_translation with Quat::normalize first (usd_import.rs:1889, :1778-1784), f32."""
+    x, y, z, w = (f32(v) for v in q_xyzw)
+    inv = f32(1.0) / f32(np.sqrt(f32(f32(f32(x * x + y * y) + z * z) + w * w)))
+    x, y, z, w = f32(x * inv), f32(y * inv), f32(z * inv), f32(w * inv)
+    x2, y2, z2 = f32(x + x), f32(y + y), f32(z + z)
+    xx, xy, xz = f32(x * x2), f32(x * y2), f32(x * z2)
+    yy, yz, zz = f32(y * y2), f32(y * z2), f32(z * z2)
+    wx, wy, wz = f32(w * x2), f32(w * y2), f32(w * z2)
+    m = _m4()
+    sx, sy, sz = (f32(v) for v in scale)
+    m[0:3, 0] = np.array([f32(1.0) - f32(yy + zz), f32(xy + wz), f32(xz - wy)], dtype=np.float32) * sx
+    m[0:3, 1] = np.array([f32(xy - wz), f32(1.0) - f32(xx + zz), f32(yz + wx)], dtype=np.float32) * sy
+    m[0:3, 2] = np.array([f32(xz + wy), f32(yz - wx), f32(1.0) - f32(xx + yy)], dtype=np.float32) * sz
+    m[0:3, 3] = np.asarray(t, dtype=np.float32)
+    return m
+
+
 def affine12(m4):
     """Affine3A::from_mat4 as the 12-float layout of the C ABI (columns x, y, z, translation)."""
     return np.concatenate([m4[0:3, 0], m4[0:3, 1], m4[0:3, 2], m4[0:3, 3]]).astype(np.float32)
@@ -361,6 +379,8 @@ def _triangulate(counts, indices, n_verts):  # usd_import.rs:1164-1214
 
 def _material_of(prim, by_path):
     target = prim.rels.get("material:binding")
+    if isinstance(target, (list, tuple)):
+        target = target[0] if target else None
     if not target:
         return DEFAULT_MATERIAL  # unbound prims (usd_import.rs:2544-2546)
     mat = by_path.get(target)
@@ -401,8 +421,13 @@ def _lux_emission(prim):  # usd_import.rs:2252-2258
 def load(path, width=None, height=None):
     """Reads a .usda file into a SceneDesc. width/height override the RenderSettings resolution BEFORE the
     camera is built (the aspect ratio feeds Camera::new; the reference can only do this by editing the USD)."""
-    with open(path, "r") as f:
-        meta, roots = parse(f.read())
+    with open(path, "rb") as f:
+        raw = f.read()
+    if raw[:8] == b"PXR-USDC":  # binary crate (SURVEY §8 f3): same Prim trees from the crate reader
+        from . import usdc
+        meta, roots = usdc.parse(raw)
+    else:
+        meta, roots = parse(raw.decode("utf-8"))
     desc = SceneDesc()
 
     by_path = {}
@@ -448,26 +473,114 @@ def load(path, width=None, height=None):
     pending = []   # deferred mesh placements (usd_import.rs:986-1003)
     slots = []     # distinct meshes by content + material
     slot_by_key = {}
+    proto_of_slot = {}   # slots that exist as kernel scenes of their own -> index into desc.protos
+    sphere_protos = {}
+
+    def intern_mesh(prim, mat):
+        """MeshArena::intern (usd_import.rs:855-915): distinct meshes by content + material."""
+        pts = prim.attr("points")
+        counts, idx = prim.attr("faceVertexCounts"), prim.attr("faceVertexIndices")
+        if pts is None or counts is None or idx is None:
+            return None
+        pts = np.asarray(pts, dtype=np.float32).reshape(-1, 3)
+        counts, idx = np.asarray(counts), np.asarray(idx)
+        key = (pts.tobytes(), counts.tobytes(), idx.tobytes(), mat.get("_path", id(mat)))
+        slot = slot_by_key.get(key)
+        if slot is None:
+            tris = _triangulate(counts, idx, pts.shape[0])
+            if tris.shape[0] == 0:
+                return None
+            slot = len(slots)
+            slots.append(dict(verts=pts, idx=tris, n_place=0, committed=False))
+            slot_by_key[key] = slot
+        return slot
+
+    def committed_proto(slot):
+        """MeshArena::committed_scene: the slot as a kernel scene of its own (never baked afterwards)."""
+        slots[slot]["committed"] = True
+        if slot not in proto_of_slot:
+            proto_of_slot[slot] = len(desc.protos)
+            desc.protos.append(dict(verts=slots[slot]["verts"], idx=slots[slot]["idx"]))
+        return proto_of_slot[slot]
+
+    def collect_proto_parts(root):
+        """collect_proto_parts (usd_import.rs:1379-1545): the leaf geometries under a prototype root, each with its
+        root-relative placement, material and mask. The root's own transform is excluded; class prims are kept."""
+        parts, stack = [], [(root, _m4())]
+        while stack:
+            prim, parent_local = stack.pop()
+            if prim.attr("active", True) is False:
+                continue
+            this_local = _m4() if prim is root else _mul(parent_local, local_matrix(prim))
+            if prim.type == "Mesh":
+                mat = _material_of(prim, by_path)
+                slot = intern_mesh(prim, mat)
+                if slot is not None:
+                    parts.append(dict(proto=committed_proto(slot), local=this_local, material=mat, mask=_ray_mask(prim)))
+            elif prim.type == "Sphere":
+                key = ("sphere", float(f32(prim.attr("radius", 1.0))))
+                if key not in sphere_protos:
+                    sphere_protos[key] = len(desc.protos)
+                    desc.protos.append(dict(radius=key[1]))
+                parts.append(dict(proto=sphere_protos[key], local=this_local, material=_material_of(prim, by_path),
+                                  mask=_ray_mask(prim)))
+            elif prim.type == "PointInstancer":
+                raise NotImplementedError("usd: a PointInstancer nested inside a prototype (usd_import.rs:1547-1630)")
+            for c in prim.children:
+                stack.append((c, this_local))
+        return parts
+
+    def emit_point_instancer(prim, world_xf):
+        """emit_point_instancer / read_instancer (usd_import.rs:1702-1876): translate * orient * scale per instance,
+        composed under the instancer's world transform; orientationsf wins over orientations (half);
+        invisibleIds prunes by ids (the array index where ids is absent)."""
+        targets = prim.rels.get("prototypes") or []
+        proto_indices = prim.attr("protoIndices")
+        if not len(targets) or proto_indices is None:
+            return
+        proto_indices = np.asarray(proto_indices).reshape(-1)
+        positions = np.asarray(prim.attr("positions") if prim.attr("positions") is not None else np.zeros((0, 3)), dtype=np.float32).reshape(-1, 3)
+        scales = prim.attr("scales")
+        scales = None if scales is None else np.asarray(scales, dtype=np.float32).reshape(-1, 3)
+        quats = prim.attr("orientationsf") if prim.attr("orientationsf") is not None else prim.attr("orientations")
+        quats = None if quats is None else np.asarray(quats, dtype=np.float32).reshape(-1, 4)  # memory order x, y, z, w
+        ids = prim.attr("ids")
+        invisible = set(int(x) for x in (prim.attr("invisibleIds") if prim.attr("invisibleIds") is not None else []))
+        parts_of = {}
+        for i, k in enumerate(proto_indices):
+            if i >= positions.shape[0]:
+                break
+            ident = int(ids[i]) if (ids is not None and i < len(ids)) else i
+            if ident in invisible:
+                continue
+            k = int(k)
+            if k < 0 or k >= len(targets):
+                continue
+            if k not in parts_of:
+                root = by_path.get(targets[k])
+                parts_of[k] = collect_proto_parts(root) if root is not None else []
+            sc = scales[i] if (scales is not None and i < scales.shape[0]) else np.ones(3, dtype=np.float32)
+            q = quats[i] if (quats is not None and i < quats.shape[0]) else np.array([0, 0, 0, 1], dtype=np.float32)
+            xf = _mul(world_xf, _from_scale_rotation_translation(sc, q, positions[i]))
+            for part in parts_of[k]:
+                m = _mul(xf, part["local"])
+                if abs(float(np.linalg.det(m.astype(np.float64)))) < 1e-12:
+                    continue  # attach_proto_parts: a zero scale hides an instance
+                desc.geoms.append(dict(kind="instance", proto=part["proto"], l2w=affine12(m), mask=part["mask"],
+                                       material=part["material"], name=prim.name))
 
     def visit(prim, parent_world):
+        """Returns the prim's world matrix, or None when its subtree is not traversed."""
         local = local_matrix(prim)
         world = _mul(parent_world, local)
         t = prim.type
+        if t == "PointInstancer":
+            emit_point_instancer(prim, world)
+            return None  # prototypes are drawn through the instancer, never on their own (usd_import.rs:205-207)
         if t == "Mesh":
-            pts = prim.attr("points")
-            counts, idx = prim.attr("faceVertexCounts"), prim.attr("faceVertexIndices")
-            if pts is not None and counts is not None and idx is not None:
-                mat = _material_of(prim, by_path)
-                pts = np.asarray(pts, dtype=np.float32).reshape(-1, 3)
-                key = (pts.tobytes(), tuple(counts), tuple(idx), mat.get("_path", id(mat)))
-                slot = slot_by_key.get(key)
-                if slot is None:
-                    tris = _triangulate(counts, idx, pts.shape[0])
-                    if tris.shape[0] == 0:
-                        return world
-                    slot = len(slots)
-                    slots.append(dict(verts=pts, idx=tris, n_place=0))
-                    slot_by_key[key] = slot
+            mat = _material_of(prim, by_path)
+            slot = intern_mesh(prim, mat)
+            if slot is not None:
                 slots[slot]["n_place"] += 1
                 gid = len(desc.geoms)
                 desc.geoms.append(dict(kind="pending", mask=_ray_mask(prim), material=mat, name=prim.name))
@@ -512,6 +625,8 @@ def load(path, width=None, height=None):
             if prim.spec == "class" or prim.attr("active", True) is False:
                 continue
             world = visit(prim, parent_world)
+            if world is None:
+                continue
             for c in prim.children:
                 stack.append((c, world))
 
@@ -532,12 +647,11 @@ def load(path, width=None, height=None):
                 traverse([ch], identity)
 
     # flush_meshes (usd_import.rs:1034-1089): sole placement -> baked into world space; else instanced
-    proto_of_slot = {}
     for gid, slot, world in pending:
         sl = slots[slot]
         g = desc.geoms[gid]
         m3 = world[0:3, 0:3].astype(np.float64)
-        if sl["n_place"] == 1:
+        if sl["n_place"] == 1 and not sl["committed"]:
             idx = sl["idx"].copy()
             if np.linalg.det(m3) < 0.0:  # bake_indices: mirrored placement swaps the winding
                 idx[:, [1, 2]] = idx[:, [2, 1]]
@@ -593,9 +707,12 @@ def build_world(desc, api, new_material):
     """Feeds a SceneDesc through a SceneBuilder-shaped API (WorldBuilder::attach_masked + commit,
     rt_world.rs:111-185). Returns (scene, materials[list of ctypes structs], protos)."""
     protos = []
-    for p in desc.protos:  # MeshArena::committed_scene, usd_import.rs:891-909
+    for p in desc.protos:  # MeshArena::committed_scene, usd_import.rs:891-909; local sphere parts :1462-1484
         b = api.SceneBuilder()
-        b.attach_triangles(p["verts"], p["idx"])
+        if "radius" in p:
+            b.attach_sphere((0.0, 0.0, 0.0), float(p["radius"]))
+        else:
+            b.attach_triangles(p["verts"], p["idx"])
         protos.append(b.commit())
     b = api.SceneBuilder()
     materials = []

@@ -45,6 +45,20 @@ def test_image_and_counters_identical_to_oracle(crt, name, w, h, spp, depth):
     assert bad.shape[0] == 0, f"{name}: {bad.shape[0]} differing components, first {bad[:3]}"
 
 
+def test_medcity_crate_identical_to_oracle(crt):
+    """BASELINE config 5's own file (binary USDC, PointInstancer with 40 000 instances of 8 prototypes), read by the
+    crate reader: image and counters identical to the oracle."""
+    import torch
+    r, desc = crt.load_usda(os.path.join(ROOT, "scenes", "PointInstancedMedCity.usd"), 96, 54, 6)
+    r.render_samples(0, 4)
+    torch.cuda.synchronize()
+    img, st = r.image(), r.stats()
+    oimg, ost = ora_world.OracleRenderer(desc, crt.usda, max_depth=6).render(4, forward=1)
+    for f, _t in ora.RayStats._fields_:
+        assert getattr(st, f) == getattr(ost, f), f
+    assert st.closest_hit > st.camera_rays and np.array_equal(img.view(np.uint32), oimg.view(np.uint32))
+
+
 def test_synthetic_city_identical_to_oracle(crt):
     """The labelled stand-in for BASELINE config 5 (instancing-heavy): 576 instances of four prototypes, two sphere
     lights, five material variants — image and counters identical to the oracle."""
