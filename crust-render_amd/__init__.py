@@ -671,6 +671,8 @@ def load_usda(path, width=None, height=None, max_depth=None, rank=0, world=1, va
     r._protos = protos
     return r, desc
 
+load_scene = load_usda  # the same loader under the name that fits all it reads (.usda, .usd/.usdc crates, synthetic:*)
+
 from . import usda  # noqa: E402,F401  (the minimal USDA reader)
 from . import usdc  # noqa: E402,F401  (the USDC crate reader)
 from . import shard  # noqa: E402,F401  (pixel-tile sharding + the tile gather)

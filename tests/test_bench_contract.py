@@ -34,3 +34,16 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
     # rays are counted as the reference counts them (stats.rs:150-152)
     assert d["config"]["rays_total"] == d["config"]["closest_hit"] + d["config"]["shadow_rays"]
+
+
+@pytest.mark.gpu
+def test_auxiliary_benchmarks_run():
+    """bench_kernels.py (the reference's kernel probe) and bench_published.py print well-formed JSON."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench_kernels.py"), "--rays", "65536", "--reps", "1"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads(res.stdout)
+    assert set(d["scenes"]) == {"tri_spheres", "sphere_grid", "instances"}
+    for e in d["scenes"].values():
+        for q in ("intersect", "occluded"):
+            assert e[q]["gpu_mray_s"] > 0 and e[q]["hits"] > 0 and e[q]["oracle_1t_mray_s"] > 0
