@@ -118,14 +118,17 @@ struct DevPrim {  // 64 bytes
 static_assert(sizeof(DevPrim) == 64, "");
 
 struct DevInstance {  // 192 bytes
-  float w2l[12];      // cached world-to-local at time 0 (prim.rs:266)
-  float nmat[9];      // inverse transpose (prim.rs:267)
+  float w2l[12];      // cached world-to-local at time 0 (prim.rs:266); its matrix3 transposed is the normal matrix (:267)
   uint32_t root;      // absolute node index of the instanced scene's root
-  uint32_t has_packets;
-  uint32_t has_end;   // transform motion blur (prim.rs:276)
+  uint32_t flags;     // bit 0: the instanced tree has Tri4 packets; bit 1: transform motion blur (prim.rs:276)
+  uint32_t geom_id;   // the instance's own geometry id and ray mask: a leaf's index list addresses an instance
+  uint32_t mask;      //   record directly (kIndexInstance), so entering one never touches its DevPrim
   float l2w[12];
   float l2w_end[12];
+  uint32_t pad[8];
 };
+// Entries of `indices` (a leaf's scalar list): primitive index, or kIndexInstance | instance slot.
+constexpr uint32_t kIndexInstance = 0x80000000u;
 static_assert(sizeof(DevInstance) == 192, "");
 
 struct DevScene {

@@ -498,9 +498,49 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
         const uint32_t pi = S.indices[cursor];
         cursor++;
         rem--;
+        bool occluded = false;
+        if (pi & kIndexInstance) {  // prim.rs:345-378 — the list entry IS the instance record's slot
+          const uint32_t inst = pi & ~kIndexInstance;
+          const DevInstance *in = &S.instances[inst];
+          const uint4 ih = *reinterpret_cast<const uint4 *>(&in->root);  // root, flags, geom_id, mask
+          if ((rmask & ih.w) != 0) {  // prim.rs:52-54
+            if (level + 1 >= (uint32_t)kMaxLevels) err |= 2u;
+            else {
+              float w2l[12];
+              if ((ih.y & 2u) && time > 0.0f) motion_w2l(*in, time, w2l);
+              else {
+#pragma unroll
+                for (int i = 0; i < 12; i++) w2l[i] = in->w2l[i];
+              }
+              Frame &f = frames[row][level];
+              f.ox = g0.x; f.oy = g0.y; f.oz = g0.z; f.dx = dx; f.dy = dy; f.dz = dz;
+              f.cursor = cursor; f.cend = rem; f.base = base; f.inst = inst; f.geom = ih.z; f.has_packets = hp;
+              // transform_point3a / transform_vector3a: ((x_axis*v.x + y_axis*v.y) + z_axis*v.z) [+ translation]
+              float px = w2l[0] * g0.x, py = w2l[1] * g0.x, pz = w2l[2] * g0.x;
+              px = px + w2l[3] * g0.y; py = py + w2l[4] * g0.y; pz = pz + w2l[5] * g0.y;
+              px = px + w2l[6] * g0.z; py = py + w2l[7] * g0.z; pz = pz + w2l[8] * g0.z;
+              px = px + w2l[9]; py = py + w2l[10]; pz = pz + w2l[11];
+              float qx = w2l[0] * dx, qy = w2l[1] * dx, qz = w2l[2] * dx;
+              qx = qx + w2l[3] * dy; qy = qy + w2l[4] * dy; qz = qz + w2l[5] * dy;
+              qx = qx + w2l[6] * dz; qy = qy + w2l[7] * dz; qz = qz + w2l[8] * dz;
+              RayCtx r;
+              r.ox = px; r.oy = py; r.oz = pz; r.dx = qx; r.dy = qy; r.dz = qz;  // unnormalised: local t == world t
+              side_d[row][0] = qx; side_d[row][1] = qy; side_d[row][2] = qz;
+              level++;
+              aux &= ~(1u << level);
+              base = sp;
+              cursor = 0;
+              rem = 0;
+              uint32_t kz, swap;
+              store_ray(row, r, (ih.y & 1u) != 0, closest, kz, swap);
+              c = ctl_pack(sp, base, level, ih.y & 1u, kz, swap, 0);
+              if (STATS) { st.descents++; st.queries[1]++; }
+              push(row, sp, ih.x);
+            }
+          }
+        } else {
         const DevPrim *p = &S.prims[pi];
         const uint4 hd = *reinterpret_cast<const uint4 *>(p);  // kind, geom_id, prim_id, mask
-        bool occluded = false;
         if ((rmask & hd.w) != 0) {  // prim.rs:52-54
           if (hd.x == PRIM_SPHERE) {  // prim.rs:133-161
             const float4 s = *reinterpret_cast<const float4 *>(p->d);
@@ -532,42 +572,6 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
                 }
               }
             }
-          } else if (hd.x == PRIM_INSTANCE) {  // prim.rs:345-378
-            if (level + 1 >= (uint32_t)kMaxLevels) err |= 2u;
-            else {
-              const uint32_t inst = __float_as_uint(p->d[0]);
-              const DevInstance *in = &S.instances[inst];
-              float w2l[12];
-              if (in->has_end && time > 0.0f) motion_w2l(*in, time, w2l);
-              else {
-#pragma unroll
-                for (int i = 0; i < 12; i++) w2l[i] = in->w2l[i];
-              }
-              Frame &f = frames[row][level];
-              f.ox = g0.x; f.oy = g0.y; f.oz = g0.z; f.dx = dx; f.dy = dy; f.dz = dz;
-              f.cursor = cursor; f.cend = rem; f.base = base; f.inst = inst; f.geom = hd.y; f.has_packets = hp;
-              // transform_point3a / transform_vector3a: ((x_axis*v.x + y_axis*v.y) + z_axis*v.z) [+ translation]
-              float px = w2l[0] * g0.x, py = w2l[1] * g0.x, pz = w2l[2] * g0.x;
-              px = px + w2l[3] * g0.y; py = py + w2l[4] * g0.y; pz = pz + w2l[5] * g0.y;
-              px = px + w2l[6] * g0.z; py = py + w2l[7] * g0.z; pz = pz + w2l[8] * g0.z;
-              px = px + w2l[9]; py = py + w2l[10]; pz = pz + w2l[11];
-              float qx = w2l[0] * dx, qy = w2l[1] * dx, qz = w2l[2] * dx;
-              qx = qx + w2l[3] * dy; qy = qy + w2l[4] * dy; qz = qz + w2l[5] * dy;
-              qx = qx + w2l[6] * dz; qy = qy + w2l[7] * dz; qz = qz + w2l[8] * dz;
-              RayCtx r;
-              r.ox = px; r.oy = py; r.oz = pz; r.dx = qx; r.dy = qy; r.dz = qz;  // unnormalised: local t == world t
-              side_d[row][0] = qx; side_d[row][1] = qy; side_d[row][2] = qz;
-              level++;
-              aux &= ~(1u << level);
-              base = sp;
-              cursor = 0;
-              rem = 0;
-              uint32_t kz, swap;
-              store_ray(row, r, in->has_packets != 0, closest, kz, swap);
-              c = ctl_pack(sp, base, level, in->has_packets ? 1u : 0u, kz, swap, 0);
-              if (STATS) { st.descents++; st.queries[1]++; }
-              push(row, sp, in->root);
-            }
           } else {
             // A triangle on the scalar list (the builder always packs triangles; kept for completeness).
             RayCtx rr;
@@ -591,6 +595,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
               }
             }
           }
+        }
         }
         if (occluded) { aux |= 1u; next = PH_EMIT; }
         else next = advance(row, sp, base, level, rem, cur, cursor);
@@ -627,7 +632,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
           }
           const DevInstance *in = &S.instances[f.inst];
           float nm[9];
-          if (in->has_end && time > 0.0f) {
+          if ((in->flags & 2u) && time > 0.0f) {
             float w2l[12];
             motion_w2l(*in, time, w2l);
             // normal matrix = w2l.matrix3 transposed (prim.rs:327)
@@ -635,8 +640,9 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
             nm[3] = w2l[1]; nm[4] = w2l[4]; nm[5] = w2l[7];
             nm[6] = w2l[2]; nm[7] = w2l[5]; nm[8] = w2l[8];
           } else {
-#pragma unroll
-            for (int i = 0; i < 9; i++) nm[i] = in->nmat[i];
+            nm[0] = in->w2l[0]; nm[1] = in->w2l[3]; nm[2] = in->w2l[6];  // cached normal matrix = w2l.matrix3 transposed
+            nm[3] = in->w2l[1]; nm[4] = in->w2l[4]; nm[5] = in->w2l[7];
+            nm[6] = in->w2l[2]; nm[7] = in->w2l[5]; nm[8] = in->w2l[8];
           }
           float x = nm[0] * bnx, y = nm[1] * bnx, z = nm[2] * bnx;
           x = x + nm[3] * bny; y = y + nm[4] * bny; z = z + nm[5] * bny;

@@ -206,7 +206,7 @@ Flat::Placed place(Flat &f, const Scene &s) {
       if (p.active & (1u << l)) p.prim[l] += prim0;
     f.packets.push_back(p);
   }
-  for (uint32_t i : b.indices) f.indices.push_back(i + prim0);
+  std::vector<uint32_t> inst_slot(b.prims.size(), CRT_INVALID_ID);
   for (size_t i = 0; i < b.prims.size(); i++) {
     const Prim &p = b.prims[i];
     DevPrim d{};
@@ -229,19 +229,20 @@ Flat::Placed place(Flat &f, const Scene &s) {
     } else {
       DevInstance in{};
       put_affine(in.w2l, p.w2l);
-      const float nm[9] = {p.normal_mat.x.x, p.normal_mat.x.y, p.normal_mat.x.z, p.normal_mat.y.x, p.normal_mat.y.y,
-                           p.normal_mat.y.z, p.normal_mat.z.x, p.normal_mat.z.y, p.normal_mat.z.z};
-      std::memcpy(in.nmat, nm, sizeof nm);
       in.root = inner[i].root;
-      in.has_packets = inner[i].has_packets;
-      in.has_end = p.has_end ? 1u : 0u;
+      in.flags = (inner[i].has_packets ? 1u : 0u) | (p.has_end ? 2u : 0u);
+      in.geom_id = p.geom_id;
+      in.mask = p.mask;
       put_affine(in.l2w, p.l2w);
       put_affine(in.l2w_end, p.has_end ? p.l2w_end : p.l2w);
-      d.d[0] = u2f(uint32_t(f.instances.size()));
+      inst_slot[i] = uint32_t(f.instances.size());
+      d.d[0] = u2f(inst_slot[i]);
       f.instances.push_back(in);
     }
     f.prims.push_back(d);
   }
+  for (uint32_t i : b.indices)  // scalar lists: primitives by index, instances by their record
+    f.indices.push_back(b.prims[i].kind == PRIM_INSTANCE ? (kIndexInstance | inst_slot[i]) : (i + prim0));
   Flat::Placed me{b.wide.empty() ? CRT_INVALID_ID : node0, b.packets.empty() ? 0u : 1u};
   f.placed.emplace(&s, me);
   return me;
