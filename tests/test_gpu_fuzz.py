@@ -11,7 +11,12 @@ pytestmark = pytest.mark.gpu
 f32 = np.float32
 
 
-@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16, 17, 18])
+import os
+
+_EXTRA = int(os.environ.get("CRT_FUZZ_EXTRA", "0"))  # CRT_FUZZ_EXTRA=N: N more seeds per test (soak runs)
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16, 17, 18] + list(range(1000, 1000 + _EXTRA)))
 def test_random_scene_matches_oracle_bitwise(crt, seed):
     import torch
     recipe = fuzz_scenes.recipe(seed)
@@ -47,7 +52,7 @@ def test_random_scene_matches_oracle_bitwise(crt, seed):
         assert np.array_equal(got_occ.cpu().numpy().astype(np.uint8), occ)
 
 
-@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106, 107, 108, 109, 110])
+@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106, 107, 108, 109, 110] + list(range(2000, 2000 + _EXTRA)))
 def test_random_world_renders_identically(crt, seed):
     """Random OpenPBR materials (every lobe, interior media, thin walls, dispersion, thin film, emission), sphere and
     rect lights, all four sampling strategies, both filters, thin-lens cameras: image and counters identical."""
