@@ -116,7 +116,7 @@ class CrtMaterial(C.Structure):
 
 
 MAT_OPENPBR, MAT_EMISSIVE = 0, 1
-LIGHT_SPHERE, LIGHT_RECT = 0, 1
+LIGHT_SPHERE, LIGHT_RECT, LIGHT_DISTANT, LIGHT_DOME = 0, 1, 2, 3
 STRATEGY = {"power": 0, "mis": 0, "balance": 1, "light": 2, "bsdf": 3}
 FILTER = {"box": 0, "triangle": 1}
 
@@ -539,10 +539,17 @@ def make_lights(light_dicts):
     arr = (CrtLight * max(len(light_dicts), 1))()
     for k, d in enumerate(light_dicts):
         l = arr[k]
-        l.kind = LIGHT_SPHERE if d["kind"] == "sphere" else LIGHT_RECT
+        l.kind = {"sphere": LIGHT_SPHERE, "rect": LIGHT_RECT, "distant": LIGHT_DISTANT,
+                  "dome": LIGHT_DOME}[d["kind"]]
         l.geom_id = int(d["geom_id"])
         l.radiance[:] = [float(x) for x in d["radiance"]]
-        if d["kind"] == "sphere":
+        if d["kind"] == "distant":  # derived form, see include/crt.h
+            l.normal[:] = [float(x) for x in d["direction"]]
+            l.radius = float(d["cos_half_angle"])
+            l.center[0] = float(d["solid_angle"])
+        elif d["kind"] == "dome":
+            pass
+        elif d["kind"] == "sphere":
             l.center[:] = [float(x) for x in d["center"]]
             l.radius = float(d["radius"])
         else:

@@ -131,6 +131,7 @@ struct Params {
   const DevMedium *media_by_id;    // the present ones, by compact id - 1
   const CrtLight *lights;
   uint32_t n_lights;
+  uint32_t has_inf_lights;  // any DISTANT / DOME entry: escaping rays then run escaped_emission
   CrtCamera camera;
   uint32_t width, height, max_depth;
   int32_t frame, strategy, filter_kind;
@@ -160,6 +161,31 @@ __device__ __forceinline__ float bounce_weight(int s, float bounce_pdf, float li
     case CRT_STRATEGY_LIGHT: return 0.0f;
     default: return 1.0f;
   }
+}
+// What an escaping ray picks up (tracer.rs:1321-1342 with escaped_emission, :966-1009): every light at infinity
+// covering the direction, MIS-weighted against the previous vertex's NEE; the sky gradient only where none covers.
+__device__ __forceinline__ V3 sky_gradient(V3 unit_direction) {
+  const float t = 0.5f * (unit_direction.y + 1.0f);
+  return v3(1.0f, 1.0f, 1.0f) * (1.0f - t) + v3(0.5f, 0.7f, 1.0f) * t;
+}
+__device__ __forceinline__ V3 escaped_background(const CrtLight *lights, uint32_t n_lights, int strategy,
+                                                 V3 unit_direction, bool competing, float prev_pdf) {
+  V3 background = splat(0.0f);
+  bool covered = false;
+  for (uint32_t k = 0; k < n_lights; k++) {
+    V3 emitted;
+    float pdf;
+    if (!light_escaped(lights[k], unit_direction, emitted, pdf)) continue;
+    covered = true;
+    float weight = 1.0f;
+    if (competing && strategy != CRT_STRATEGY_BSDF) {
+      const float light_pdf = rmax(pdf / (float)n_lights, 1e-6f);
+      weight = bounce_weight(strategy, prev_pdf, light_pdf);
+    }
+    background = background + emitted * weight;
+  }
+  if (!covered) background = background + sky_gradient(unit_direction);
+  return background;
 }
 
 __device__ __forceinline__ bool lds_take(bool want, uint32_t *next, uint32_t limit, uint32_t &idx) {
@@ -327,7 +353,7 @@ __global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_extend(Params P, P
 // ---- shade: one iteration of trace_path's loop body for every live path (tracer.rs:1118-1530) ----
 // MEDIA: some material of the scene has an interior medium; scenes without one run the leaner instance (the medium
 // code costs k_shade 80 spilled VGPRs at three waves per SIMD).
-template <bool MEDIA>
+template <bool MEDIA, bool INF>
 __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S, const PathSoA &N, const HitSoA &H,
                                               const ShadowSoA &Q, Counters *C, int cur, float4 *staging,
                                               uint32_t *sobol_tab /* kSobolLdsWords */) {
@@ -371,16 +397,16 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
         const uint32_t hg = H.geom[i_c];
         const int remaining = (int)(D.z >> 16);
         const bool carries_medium = MEDIA && (D.w >> kMediumShift) != 0;
-        if (hg == kInvalid && remaining > 0 && !carries_medium) {
-          // tracer.rs:1321-1342: background = sky gradient (no light at infinity in scope); the path ends here
+        if (!INF && hg == kInvalid && remaining > 0 && !carries_medium) {
+          // tracer.rs:1321-1342: the path ends on the sky gradient. (With lights at infinity — INF — escaped rays
+          // take the full vertex step instead: their background is a loop over the light list.)
           const float4 A = S.a[i_c], B = S.b[i_c], Cc = S.c[i_c];
           const V3 rd = v3(A.w, B.x, B.y), beta = v3(B.z, B.w, Cc.x);
           V3 L = v3(Cc.y, Cc.z, Cc.w);
           s_closest++;
           s_esc++;
           const V3 unit_direction = normalize(rd);
-          const float t = 0.5f * (unit_direction.y + 1.0f);
-          const V3 background = splat(0.0f) + (v3(1.0f, 1.0f, 1.0f) * (1.0f - t) + v3(0.5f, 0.7f, 1.0f) * t);
+          const V3 background = splat(0.0f) + sky_gradient(unit_direction);
           L = L + beta * background;
           staging[(D.w & 0xffffu) * P.n_act + D.y] = make_float4(L.x, L.y, L.z, 0.0f);
         } else {
@@ -497,11 +523,12 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
             alive = true;
             n_o = pos; n_d = dir; n_ppdf = 0.0f; n_delta = false; n_prev_valid = false;  // same medium: n_med stays
           }
-        } else if (!has_hit) {  // tracer.rs:1321-1342: background = sky gradient (no light at infinity in scope)
+        } else if (!has_hit) {  // tracer.rs:1321-1342 (rays that carried a medium out of the scene end here)
           s_esc++;
           const V3 unit_direction = normalize(rd);
-          const float t = 0.5f * (unit_direction.y + 1.0f);
-          const V3 background = splat(0.0f) + (v3(1.0f, 1.0f, 1.0f) * (1.0f - t) + v3(0.5f, 0.7f, 1.0f) * t);
+          const V3 background = INF ? escaped_background(P.lights, P.n_lights, P.strategy, unit_direction,
+                                                        prev_valid && !prev_delta, S.e[i].w)
+                                    : splat(0.0f) + sky_gradient(unit_direction);
           L = L + beta * background;
         } else {
           const CrtMaterial &mat = P.materials[geom];
@@ -527,7 +554,7 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
             if (li > P.n_lights - 1) li = P.n_lights - 1;
             const CrtLight &light = P.lights[li];
             LightSample ls;
-            if (light_sample_li(light, rec.p, nee_s[1], nee_s[2], ls)) {
+            if (light_sample_li<INF>(light, rec.p, nee_s[1], nee_s[2], ls)) {
               s_shadow++;  // the reference traces the shadow ray before it evaluates the BSDF (tracer.rs:1412-1425)
               want_shadow = true;
               sh_d = ls.direction;
@@ -625,11 +652,11 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
   if (threadIdx.x >= 1 && threadIdx.x <= 7 && lds_ctr[threadIdx.x + 1])
     atomicAdd(&C->stats[threadIdx.x], (unsigned long long)lds_ctr[threadIdx.x + 1]);
 }
-template <bool MEDIA>
+template <bool MEDIA, bool INF>
 __global__ __launch_bounds__(kBlock, CRT_SHADE_WAVES) void k_shade(Params P, PathSoA S, PathSoA N, HitSoA H, ShadowSoA Q, Counters *C,
                                                   int cur, float4 *staging) {
   __shared__ uint32_t sobol_tab[kSobolLdsWords];
-  shade_segment<MEDIA>(P, S, N, H, Q, C, cur, staging, sobol_tab);
+  shade_segment<MEDIA, INF>(P, S, N, H, Q, C, cur, staging, sobol_tab);
 }
 
 // ---- shadow: World::occluded (rt_world.rs:235-237) for the queue; unoccluded requests pay out ----
@@ -684,7 +711,7 @@ __global__ __launch_bounds__(kBlock, CRT_SHADOW_WAVES) void k_shadow(Params P, P
 // barrier separates the stages: no grid-wide barrier, no launch per bounce, and workgroups drift apart freely — while
 // one is shading (VALU-bound) its neighbours on the same SIMDs are traversing (latency-bound). A workgroup leaves as
 // soon as its segment is empty. LIT: the scene has lights and the strategy samples them (shadow stage present). ----
-template <bool MEDIA, bool LIT>
+template <bool MEDIA, bool LIT, bool INF>
 __global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_path(Params P, PathSoA S0, PathSoA S1, HitSoA H, ShadowSoA Q, Counters *C,
                                                  float4 *staging, uint32_t sample_begin, uint32_t n_samples) {
   __shared__ __attribute__((aligned(16))) uint32_t arena[kArenaDwords];
@@ -697,7 +724,7 @@ __global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_path(Params P, Pat
     const PathSoA &N = cur ? S0 : S1;
     extend_segment<false>(P, S, H, C, cur, it == 0 ? 1 : 0, nullptr, arena);
     __syncthreads();  // hit records of this segment are complete; the arena changes hands
-    shade_segment<MEDIA>(P, S, N, H, Q, C, cur, staging, arena);
+    shade_segment<MEDIA, INF>(P, S, N, H, Q, C, cur, staging, arena);
     __syncthreads();
     if (LIT) {
       shadow_segment<false>(P, N, Q, C, staging, nullptr, arena);
@@ -935,13 +962,20 @@ struct Renderer {
     const bool lit = P.n_lights > 0 && P.strategy != CRT_STRATEGY_BSDF;
     if (fused && !d_tstats) {  // one launch for the whole path loop (class 0 of the profile), then the film fold
       timed(0, st, [&] {
-        if (has_media) {
-          if (lit) hipLaunchKernelGGL((k_path<true, true>), dim3(grid), dim3(kBlock), 0, st, p, S[0], S[1], H, Q, C, staging, sample_begin, n_samples);
-          else hipLaunchKernelGGL((k_path<true, false>), dim3(grid), dim3(kBlock), 0, st, p, S[0], S[1], H, Q, C, staging, sample_begin, n_samples);
-        } else {
-          if (lit) hipLaunchKernelGGL((k_path<false, true>), dim3(grid), dim3(kBlock), 0, st, p, S[0], S[1], H, Q, C, staging, sample_begin, n_samples);
-          else hipLaunchKernelGGL((k_path<false, false>), dim3(grid), dim3(kBlock), 0, st, p, S[0], S[1], H, Q, C, staging, sample_begin, n_samples);
+#define CRT_PATH(M, L, I) \
+  hipLaunchKernelGGL((k_path<M, L, I>), dim3(grid), dim3(kBlock), 0, st, p, S[0], S[1], H, Q, C, staging, sample_begin, n_samples)
+        const int variant = (has_media ? 4 : 0) | (lit ? 2 : 0) | (P.has_inf_lights ? 1 : 0);
+        switch (variant) {
+          case 0: CRT_PATH(false, false, false); break;
+          case 1: CRT_PATH(false, false, true); break;
+          case 2: CRT_PATH(false, true, false); break;
+          case 3: CRT_PATH(false, true, true); break;
+          case 4: CRT_PATH(true, false, false); break;
+          case 5: CRT_PATH(true, false, true); break;
+          case 6: CRT_PATH(true, true, false); break;
+          default: CRT_PATH(true, true, true); break;
         }
+#undef CRT_PATH
       });
       return fold();
     }
@@ -950,8 +984,11 @@ struct Renderer {
     for (uint32_t it = 0; it <= P.max_depth; it++) {
       if (d_tstats) timed(0, st, [&] { hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kBlock), 0, st, p, S[cur], H, C, cur, it == 0 ? 1 : 0, d_tstats); });
       else timed(0, st, [&] { hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kBlock), 0, st, p, S[cur], H, C, cur, it == 0 ? 1 : 0, d_tstats); });
-      if (has_media) timed(1, st, [&] { hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(kBlock), 0, st, p, S[cur], S[1 - cur], H, Q, C, cur, staging); });
-      else timed(1, st, [&] { hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(kBlock), 0, st, p, S[cur], S[1 - cur], H, Q, C, cur, staging); });
+#define CRT_SHADE(M, I) \
+  timed(1, st, [&] { hipLaunchKernelGGL((k_shade<M, I>), dim3(grid), dim3(kBlock), 0, st, p, S[cur], S[1 - cur], H, Q, C, cur, staging); })
+      if (has_media) { if (P.has_inf_lights) CRT_SHADE(true, true); else CRT_SHADE(true, false); }
+      else { if (P.has_inf_lights) CRT_SHADE(false, true); else CRT_SHADE(false, false); }
+#undef CRT_SHADE
       if (P.n_lights > 0 && P.strategy != CRT_STRATEGY_BSDF) {
         if (d_tstats) timed(2, st, [&] { hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(kBlock), 0, st, p, S[1 - cur], Q, C, staging, d_tstats + 1); });
         else timed(2, st, [&] { hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(kBlock), 0, st, p, S[1 - cur], Q, C, staging, d_tstats); });
@@ -1016,6 +1053,11 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
   Params &P = r.P;
   P.scene = scene->p->dev->view;
   P.n_lights = (uint32_t)n_lights;
+  P.has_inf_lights = 0;
+  for (size_t k = 0; k < n_lights; k++) {
+    if (lights[k].kind > CRT_LIGHT_DOME) return nullptr;
+    if (lights[k].kind >= CRT_LIGHT_DISTANT) P.has_inf_lights = 1;
+  }
   P.camera = *camera;
   P.width = settings->width; P.height = settings->height; P.max_depth = settings->max_depth;
   P.frame = settings->frame; P.strategy = settings->strategy; P.filter_kind = settings->filter_kind;

@@ -610,7 +610,55 @@ __device__ __forceinline__ float solid_angle_pdf(const CrtLight &l, V3 from, V3 
   const float cosine = rmax(dot(ln, -dir_to_light), 0.0f);
   return d2 / (cosine * area + 1e-4f);
 }
+__device__ __forceinline__ V3 align_to_normal(V3 local, V3 normal) {  // common.rs:176-188
+  const V3 up = fabs_(normal.z) < 0.999f ? v3(0.0f, 0.0f, 1.0f) : v3(1.0f, 0.0f, 0.0f);
+  const V3 tangent = normalize(cross(normal, up));
+  const V3 bitangent = cross(normal, tangent);
+  return tangent * local.x + bitangent * local.y + normal * local.z;
+}
+// Light::escaped: what a ray leaving the scene along `direction` (unit) sees of a light at infinity
+// (light.rs:141-146; DistantLight :268-282, :300-303; uniform DomeLight :340-355, :385-388).
+__device__ __forceinline__ bool light_escaped(const CrtLight &l, V3 direction, V3 &radiance, float &pdf) {
+  if (l.kind == CRT_LIGHT_DISTANT) {
+    if (!(dot(direction, -ld3(l.normal)) >= l.radius)) return false;
+    const float omega = rmax(l.center[0], 1e-12f);
+    radiance = ld3(l.radiance) / omega;
+    pdf = 1.0f / omega;
+    return true;
+  }
+  if (l.kind == CRT_LIGHT_DOME) {
+    radiance = ld3(l.radiance);
+    pdf = 1.0f / (4.0f * CRT_PI);
+    return true;
+  }
+  return false;
+}
+// INF: the light list may hold lights at infinity (compiled out of the kernels of scenes that have none).
+template <bool INF>
 __device__ __forceinline__ bool light_sample_li(const CrtLight &l, V3 from, float u, float v, LightSample &out) {
+  if (INF && l.kind == CRT_LIGHT_DISTANT) {  // light.rs:285-298: uniform direction within the cone around -direction
+    const float cos_theta = 1.0f - u * (1.0f - l.radius);
+    const float sin_theta = sqrtf(rmax(1.0f - cos_theta * cos_theta, 0.0f));
+    float sp, cp;
+    sincos_det(2.0f * CRT_PI * v, sp, cp);
+    const float omega = rmax(l.center[0], 1e-12f);
+    out.direction = normalize(align_to_normal(v3(sin_theta * cp, sin_theta * sp, cos_theta), -ld3(l.normal)));
+    out.distance = CRT_INF;
+    out.radiance = ld3(l.radiance) / omega;
+    out.pdf = 1.0f / omega;
+    return true;
+  }
+  if (INF && l.kind == CRT_LIGHT_DOME) {  // light.rs:358-383 without a map: uniform over the sphere
+    const float z = 1.0f - 2.0f * u;
+    const float r = sqrtf(rmax(1.0f - z * z, 0.0f));
+    float sp, cp;
+    sincos_det((2.0f * CRT_PI) * v, sp, cp);
+    out.direction = v3(r * cp, z, r * sp);
+    out.distance = CRT_INF;
+    out.radiance = ld3(l.radiance) * splat(1.0f);
+    out.pdf = 1.0f / (4.0f * CRT_PI);
+    return true;
+  }
   V3 lp;  // light.rs:191-204
   if (l.kind == CRT_LIGHT_SPHERE) {
     const float theta = 2.0f * CRT_PI * u;

@@ -1,7 +1,7 @@
 """Minimal USDA (text USD) reader for the crust-render sample scenes.
 
 Covers exactly what samples/{cornellbox,veach_mis,openpbr_showcase}.usda author: Xform / Mesh / Sphere /
-Camera / SphereLight / RectLight / Scope / Material / Shader / RenderSettings prims, xformOp stacks,
+Camera / SphereLight / RectLight / DistantLight / DomeLight / Scope / Material / Shader / RenderSettings prims, xformOp stacks,
 `rel material:binding`, `crust:openpbr` shader inputs and the `crust:` render settings. It restates the
 importer's decisions, not a USD composition engine (no references, payloads, variants or instancing):
 
@@ -418,6 +418,27 @@ def _lux_emission(prim):  # usd_import.rs:2252-2258
     return (color * gain).astype(np.float32)
 
 
+def distant_light(direction, irradiance, angle_deg=0.53):
+    """DistantLight::new (light.rs:255-266) in its derived form: unit travel direction, the cone's cos(half angle)
+    and solid angle. Returns None for a degenerate direction (usd_import.rs:2362-2365)."""
+    d = np.asarray(direction, dtype=np.float32)
+    l2 = f32(f32(d[0] * d[0] + d[1] * d[1]) + d[2] * d[2])
+    if l2 < f32(1e-12):
+        return None
+    d = (d / np.sqrt(l2)).astype(np.float32)
+    diameter = np.clip(f32(angle_deg), f32(0.05), f32(179.0))
+    half = f32(f32(0.5) * f32(diameter * f32(np.pi / 180.0)))
+    cos_half = f32(np.cos(half, dtype=np.float32))
+    omega = f32(f32(f32(2.0) * f32(np.pi)) * f32(f32(1.0) - cos_half))
+    return dict(kind="distant", geom_id=0xFFFFFFFF, radiance=np.asarray(irradiance, dtype=np.float32), direction=d,
+                cos_half_angle=cos_half, solid_angle=omega)
+
+
+def dome_light(tint):
+    """DomeLight without an environment map (light.rs:320-390): a uniform sky of radiance `tint`."""
+    return dict(kind="dome", geom_id=0xFFFFFFFF, radiance=np.asarray(tint, dtype=np.float32))
+
+
 def load(path, width=None, height=None):
     """Reads a .usda file into a SceneDesc. width/height override the RenderSettings resolution BEFORE the
     camera is built (the aspect ratio feeds Camera::new; the reference can only do this by editing the USD)."""
@@ -615,6 +636,17 @@ def load(path, width=None, height=None):
             nn = nz / np.sqrt(f32(f32(nz[0] * nz[0] + nz[1] * nz[1]) + nz[2] * nz[2]))  # Vec3A::normalize (RectShape::new)
             desc.lights.append(dict(kind="rect", geom_id=gid, radiance=rad, origin=origin, edge_u=eu, edge_v=ev,
                                     normal=nn.astype(np.float32)))
+        elif t == "DistantLight":  # usd_import.rs:2360-2377: the light travels down its local -Z
+            light = distant_light(_xf_vec(world, (0, 0, -1)), _lux_emission(prim), prim.attr("inputs:angle", 0.53))
+            if light is not None:
+                desc.lights.append(light)
+        elif t == "DomeLight":  # usd_import.rs:2389-2460
+            if prim.attr("inputs:texture:file", None) is not None:
+                # No AssetLoader stands behind this importer: as when the reference's host declines to decode the
+                # image (usd_import.rs:2419-2426), the dome falls back to its uniform colour.
+                import warnings
+                warnings.warn(f"DomeLight {prim.name}: environment map not decoded, using the uniform colour")
+            desc.lights.append(dome_light(_lux_emission(prim)))
         return world
 
     def traverse(root_prims, root_world):

@@ -164,8 +164,12 @@ typedef struct CrtMaterial {
 } CrtMaterial;
 void crt_material_default(CrtMaterial *m);                          /* OpenPBR::default   openpbr.rs:130-173 */
 
-enum { CRT_LIGHT_SPHERE = 0, CRT_LIGHT_RECT = 1 };
-/* AreaLight{shape, material, geom_id} (light.rs:156-163) with SphereShape (:22-25) / RectShape (:52-57). */
+enum { CRT_LIGHT_SPHERE = 0, CRT_LIGHT_RECT = 1, CRT_LIGHT_DISTANT = 2, CRT_LIGHT_DOME = 3 };
+/* AreaLight{shape, material, geom_id} (light.rs:156-163) with SphereShape (:22-25) / RectShape (:52-57).
+ * The two lights at infinity reuse the record, already in their derived form and with geom_id = CRT_INVALID_ID:
+ *   DISTANT (DistantLight, light.rs:234-318): normal = unit travel direction, radiance = irradiance,
+ *           radius = cos(half angle), center[0] = cone solid angle 2*pi*(1 - cos(half angle))   (light.rs:255-266)
+ *   DOME    (DomeLight without an environment map, light.rs:320-390): radiance = tint; uniform over the sphere. */
 typedef struct CrtLight {
   uint32_t kind; uint32_t geom_id;
   float radiance[3];

@@ -160,8 +160,26 @@ static v3 trace_path(const OraRenderJob *job, const OraRay *r, OraSampler sample
     if (!has_hit) { /* tracer.rs:1321-1342 */
       stats->ended_escaped++;
       v3 unit_direction = v3_normalize(ray.dir);
-      /* escaped_emission (tracer.rs:966-1009): area lights never cover an escaping direction. */
-      v3 background = v3_add(v3_splat(0.0f), sky(unit_direction));
+      /* escaped_emission (tracer.rs:966-1009): lights at infinity covering the direction, MIS-weighted against
+       * the NEE of the previous vertex; area lights never cover an escaping direction. */
+      v3 background = v3_splat(0.0f);
+      int covered = 0;
+      if (job->n_lights > 0) {
+        int competing = prev.valid && !prev.delta; /* a vertex that scattered is evaluable: eval() is Some */
+        float n_lights = (float)job->n_lights;
+        for (uint32_t k = 0; k < job->n_lights; k++) {
+          v3 emitted; float pdf;
+          if (!ora_light_escaped(&job->lights[k], unit_direction, &emitted, &pdf)) continue;
+          covered = 1;
+          float weight = 1.0f;
+          if (competing && samples_lights(job->strategy)) {
+            float light_pdf = ora_max(pdf / n_lights, 1e-6f);
+            weight = ora_bounce_weight(job->strategy, prev.pdf, light_pdf);
+          }
+          background = v3_add(background, v3_scale(emitted, weight));
+        }
+      }
+      if (!covered) background = v3_add(background, sky(unit_direction));
       if (forward) L = v3_add(L, v3_mul(beta, background));
       else terminal = v3_add(v3_splat(0.0f), v3_mul(one, background)); /* vol_emit + vol_tr * background */
       break;

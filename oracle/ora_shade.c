@@ -766,7 +766,66 @@ static float solid_angle_pdf(const OraLight *l, v3 from, v3 light_point) { /* li
   float cosine = ora_max(v3_dot(ln, v3_neg(dir_to_light)), 0.0f);
   return d2 / (cosine * light_area(l) + 1e-4f);
 }
+v3 ora_align_to_normal(v3 local, v3 normal) { /* common.rs:176-188 */
+  v3 up = ora_abs(normal.z) < 0.999f ? v3_new(0.0f, 0.0f, 1.0f) : v3_new(1.0f, 0.0f, 0.0f);
+  v3 tangent = v3_normalize(v3_cross(normal, up));
+  v3 bitangent = v3_cross(normal, tangent);
+  return v3_add(v3_add(v3_scale(tangent, local.x), v3_scale(bitangent, local.y)), v3_scale(normal, local.z));
+}
+void ora_light_distant(OraLight *l, v3 direction, v3 irradiance, float angle_deg) { /* light.rs:255-266 */
+  memset(l, 0, sizeof *l);
+  l->kind = ORA_LIGHT_DISTANT; l->geom_id = 0xFFFFFFFFu;
+  float diameter = ora_clamp(angle_deg, 0.05f, 179.0f);
+  float half_angle = 0.5f * (diameter * (ORA_PI / 180.0f));
+  float cos_half = ora_cosf(half_angle);
+  v3 d = v3_normalize(direction);
+  set3(l->normal, d.x, d.y, d.z);
+  set3(l->radiance, irradiance.x, irradiance.y, irradiance.z);
+  l->radius = cos_half;
+  l->center[0] = 2.0f * ORA_PI * (1.0f - cos_half);
+}
+int ora_light_escaped(const OraLight *l, v3 direction, v3 *radiance, float *pdf) {
+  if (l->kind == ORA_LIGHT_DISTANT) { /* light.rs:268-282, :300-303 */
+    if (!(v3_dot(direction, v3_neg(c3(l->normal))) >= l->radius)) return 0;
+    float omega = ora_max(l->center[0], 1e-12f);
+    *radiance = v3_divs(c3(l->radiance), omega);
+    *pdf = 1.0f / omega;
+    return 1;
+  }
+  if (l->kind == ORA_LIGHT_DOME) { /* light.rs:340-355, :385-388 (no map: uniform tint, uniform sphere pdf) */
+    *radiance = c3(l->radiance);
+    *pdf = 1.0f / (4.0f * ORA_PI);
+    return 1;
+  }
+  return 0; /* light.rs:141-146: lights with geometry are found by hitting them */
+}
 int ora_light_sample_li(const OraLight *l, v3 from, float u, float v, OraLightSample *out) { /* light.rs:191-204 */
+  if (l->kind == ORA_LIGHT_DISTANT) { /* light.rs:285-298: uniform direction within the cone around -direction */
+    float cos_theta = 1.0f - u * (1.0f - l->radius);
+    float sin_theta = sqrtf(ora_max(1.0f - cos_theta * cos_theta, 0.0f));
+    float phi = 2.0f * ORA_PI * v;
+    float sp, cp;
+    ora_sincosf(phi, &sp, &cp);
+    v3 local = v3_new(sin_theta * cp, sin_theta * sp, cos_theta);
+    float omega = ora_max(l->center[0], 1e-12f);
+    out->direction = v3_normalize(ora_align_to_normal(local, v3_neg(c3(l->normal))));
+    out->distance = ORA_INF;
+    out->radiance = v3_divs(c3(l->radiance), omega);
+    out->pdf = 1.0f / omega;
+    return 1;
+  }
+  if (l->kind == ORA_LIGHT_DOME) { /* light.rs:358-383, uniform over the sphere */
+    float z = 1.0f - 2.0f * u;
+    float r = sqrtf(ora_max(1.0f - z * z, 0.0f));
+    float phi = (2.0f * ORA_PI) * v;
+    float sp, cp;
+    ora_sincosf(phi, &sp, &cp);
+    out->direction = v3_new(r * cp, z, r * sp);
+    out->distance = ORA_INF;
+    out->radiance = v3_mul(c3(l->radiance), v3_splat(1.0f));
+    out->pdf = 1.0f / (4.0f * ORA_PI);
+    return 1;
+  }
   v3 lp = light_sample_point(l, u, v);
   v3 to_light = v3_sub(lp, from);
   float distance = v3_len(to_light);
@@ -777,7 +836,10 @@ int ora_light_sample_li(const OraLight *l, v3 from, float u, float v, OraLightSa
   out->pdf = solid_angle_pdf(l, from, lp);
   return 1;
 }
-float ora_light_pdf_at_point(const OraLight *l, v3 from, v3 light_point) { return solid_angle_pdf(l, from, light_point); }
+float ora_light_pdf_at_point(const OraLight *l, v3 from, v3 light_point) {
+  if (l->kind >= ORA_LIGHT_DISTANT) return 0.0f; /* light.rs:132-134: no geometry to hit */
+  return solid_angle_pdf(l, from, light_point);
+}
 
 /* ------------------------------------------------------------------ */
 /* camera.rs                                                           */

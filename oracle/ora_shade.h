@@ -86,7 +86,10 @@ v3 ora_cosine_hemisphere(float u, float v);    /* common.rs:128-135 */
 v3 ora_concentric_disk(float u, float v);      /* common.rs:158-174 */
 
 /* light.rs: area lights */
-enum { ORA_LIGHT_SPHERE = 0, ORA_LIGHT_RECT = 1 };
+/* Lights at infinity reuse the record: DISTANT (light.rs:234-318) keeps its unit travel direction in `normal`, the
+ * irradiance in `radiance`, cos(half angle) in `radius` and the cone's solid angle in `center[0]`; DOME (uniform,
+ * light.rs:320-390 without an environment map) keeps its tint in `radiance`. geom_id is INVALID for both. */
+enum { ORA_LIGHT_SPHERE = 0, ORA_LIGHT_RECT = 1, ORA_LIGHT_DISTANT = 2, ORA_LIGHT_DOME = 3 };
 typedef struct {
   uint32_t kind; uint32_t geom_id;
   float radiance[3];
@@ -96,6 +99,9 @@ typedef struct {
 typedef struct { v3 direction; float distance; v3 radiance; float pdf; } OraLightSample; /* light.rs:90-105 */
 int ora_light_sample_li(const OraLight *l, v3 from, float u, float v, OraLightSample *out); /* light.rs:191-204 */
 float ora_light_pdf_at_point(const OraLight *l, v3 from, v3 light_point);                   /* light.rs:206-208 */
+int ora_light_escaped(const OraLight *l, v3 direction, v3 *radiance, float *pdf);            /* light.rs:141-146, :300-303, :385-388 */
+void ora_light_distant(OraLight *l, v3 direction, v3 irradiance, float angle_deg);           /* DistantLight::new light.rs:255-266 */
+v3 ora_align_to_normal(v3 local, v3 normal);                                                 /* common.rs:176-188 */
 
 /* camera.rs */
 typedef struct { v3 origin, lower_left, horizontal, vertical, u, v; float lens_radius; } OraCamera;

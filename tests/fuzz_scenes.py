@@ -112,8 +112,8 @@ def _rand_material(rng):
 
 
 def random_world(usda, seed, width=40, height=28):
-    """A SceneDesc with random OpenPBR materials on spheres, a triangle soup and a ground, one to three lights of both
-    kinds, a random strategy / filter and a random thin-lens camera."""
+    """A SceneDesc with random OpenPBR materials on spheres, a triangle soup and a ground, one to three area lights of both
+    kinds, sometimes a distant light and a uniform dome, a random strategy / filter and a random thin-lens camera."""
     rng = np.random.default_rng(seed)
     d = usda.SceneDesc()
     g = np.array([(-8, 0, -8), (8, 0, -8), (8, 0, 8), (-8, 0, 8)], dtype=np.float32)
@@ -144,6 +144,15 @@ def random_world(usda, seed, width=40, height=28):
                                 material={"_preset": "emissive", "emission_color": rad}, name="L%d" % k))
             d.lights.append(dict(kind="rect", geom_id=gid, radiance=np.array(rad, np.float32), origin=o, edge_u=eu, edge_v=ev,
                                  normal=np.array([0, -1, 0], np.float32)))
+    # Lights at infinity (own stream, so the rest of a seed's world stays what it was): a sun in about half of the
+    # worlds, a uniform dome in a third, placed anywhere in the light list.
+    inf = np.random.default_rng(seed ^ 0x5EED1234)
+    if inf.random() < 0.5:
+        sun = usda.distant_light((inf.uniform(-1, 1), inf.uniform(-1, -0.2), inf.uniform(-1, 1)),
+                                 inf.uniform(0.5, 4, 3), [0.0, 0.53, 3.0, 25.0][int(inf.integers(0, 4))])
+        d.lights.insert(int(inf.integers(0, len(d.lights) + 1)), sun)
+    if inf.random() < 0.33:
+        d.lights.insert(int(inf.integers(0, len(d.lights) + 1)), usda.dome_light(inf.uniform(0.05, 0.8, 3)))
     lookfrom = np.array([rng.uniform(-2, 2), rng.uniform(1.5, 4), rng.uniform(6, 9)], dtype=np.float32)
     d.camera = dict(lookfrom=lookfrom, lookat=np.array([0, 1, 0], np.float32), vup=np.array([0, 1, 0], np.float32),
                     vfov_deg=f32(rng.uniform(30, 70)), aspect=f32(f32(width) / f32(height)),

@@ -117,7 +117,7 @@ class Medium(C.Structure):
     _fields_ = [("sigma_a", V3), ("sigma_s", V3), ("g", C.c_float)]
 
 
-LIGHT_SPHERE, LIGHT_RECT = 0, 1
+LIGHT_SPHERE, LIGHT_RECT, LIGHT_DISTANT, LIGHT_DOME = 0, 1, 2, 3
 
 
 class Light(C.Structure):
@@ -282,6 +282,10 @@ def lib():
         getattr(L, n).restype = res
         getattr(L, n).argtypes = args
     L.ora_light_sample_li.argtypes = [C.POINTER(Light), V3, C.c_float, C.c_float, C.POINTER(LightSample)]
+    L.ora_light_escaped.argtypes = [C.POINTER(Light), V3, C.POINTER(V3), fp]
+    L.ora_light_distant.argtypes = [C.POINTER(Light), V3, V3, C.c_float]
+    L.ora_align_to_normal.restype = V3
+    L.ora_align_to_normal.argtypes = [V3, V3]
     L.ora_light_pdf_at_point.restype = C.c_float
     L.ora_light_pdf_at_point.argtypes = [C.POINTER(Light), V3, V3]
     L.ora_camera_new.argtypes = [C.POINTER(Camera), V3, V3, V3, C.c_float, C.c_float, C.c_float, C.c_float]

@@ -14,10 +14,17 @@ def make_lights(light_dicts):
     arr = (ora.Light * max(len(light_dicts), 1))()
     for k, d in enumerate(light_dicts):
         l = arr[k]
-        l.kind = ora.LIGHT_SPHERE if d["kind"] == "sphere" else ora.LIGHT_RECT
+        l.kind = {"sphere": ora.LIGHT_SPHERE, "rect": ora.LIGHT_RECT, "distant": ora.LIGHT_DISTANT,
+                  "dome": ora.LIGHT_DOME}[d["kind"]]
         l.geom_id = int(d["geom_id"])
         l.radiance[:] = [float(x) for x in d["radiance"]]
-        if d["kind"] == "sphere":
+        if d["kind"] == "distant":  # derived form, see include/crt.h
+            l.normal[:] = [float(x) for x in d["direction"]]
+            l.radius = float(d["cos_half_angle"])
+            l.center[0] = float(d["solid_angle"])
+        elif d["kind"] == "dome":
+            pass
+        elif d["kind"] == "sphere":
             l.center[:] = [float(x) for x in d["center"]]
             l.radius = float(d["radius"])
         else:

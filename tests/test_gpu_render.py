@@ -31,7 +31,7 @@ def _both(crt, name, w, h, spp, depth, batch=None):
 
 
 SCENES = [("cornellbox", 64, 64, 8, 4), ("cornellbox", 96, 54, 4, 32), ("veach_mis", 96, 54, 8, 8),
-          ("openpbr_showcase", 96, 54, 8, 12), ("cornellbox_guided", 48, 48, 8, 8)]
+          ("openpbr_showcase", 96, 54, 8, 12), ("cornellbox_guided", 48, 48, 8, 8), ("sun_sky", 96, 54, 8, 8)]
 
 
 @pytest.mark.parametrize("name,w,h,spp,depth", SCENES)
@@ -43,6 +43,28 @@ def test_image_and_counters_identical_to_oracle(crt, name, w, h, spp, depth):
     assert np.isfinite(oimg).all()
     bad = np.argwhere(img.view(np.uint32) != oimg.view(np.uint32))
     assert bad.shape[0] == 0, f"{name}: {bad.shape[0]} differing components, first {bad[:3]}"
+
+
+@pytest.mark.parametrize("strategy", ["balance", "light", "bsdf"])
+def test_lights_at_infinity_under_every_strategy(crt, strategy):
+    """sun_sky (DistantLight + uniform DomeLight + a SphereLight): escaped_emission's MIS weights and the NEE of
+    lights without geometry (tracer.rs:966-1009, light.rs:285-298, :358-383) under the other three strategies."""
+    import torch
+    desc = crt.usda.load(os.path.join(ROOT, "scenes", "sun_sky.usda"), 80, 45)
+    desc.settings["strategy"] = strategy
+    desc.settings["max_depth"] = 6
+    scene, mats, _protos = crt.usda.build_world(desc, crt, crt.default_material)
+    s = desc.settings
+    settings = crt.RenderSettings(s["width"], s["height"], s["max_depth"], s["frame"], s["strategy"], s["filter"],
+                                  s["filter_radius"], 0.0)
+    r = crt.Renderer(scene, mats, desc.lights, crt.make_camera(**desc.camera), settings)
+    r.render_samples(0, 6)
+    torch.cuda.synchronize()
+    img, st = r.image(), r.stats()
+    oimg, ost = ora_world.OracleRenderer(desc, crt.usda).render(6, forward=1)
+    for f, _t in ora.RayStats._fields_:
+        assert getattr(st, f) == getattr(ost, f), (strategy, f)
+    assert np.array_equal(img.view(np.uint32), oimg.view(np.uint32))
 
 
 def test_medcity_crate_identical_to_oracle(crt):

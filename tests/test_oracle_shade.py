@@ -510,6 +510,97 @@ def test_rect_shape_samples_lie_in_rect():  # light.rs:468-479
     assert (L.ora_t_light_normal_at(C.byref(l), p).np() == np.array([0, -1, 0], dtype=np.float32)).all()
 
 
+def distant(direction, irradiance, angle):
+    l = ora.Light()
+    L.ora_light_distant(C.byref(l), ora.v3(direction), ora.v3(irradiance), angle)
+    return l
+
+
+def escaped(l, direction):
+    rad, pdf = ora.V3(), C.c_float()
+    if not L.ora_light_escaped(C.byref(l), ora.v3(direction), C.byref(rad), C.byref(pdf)):
+        return None
+    return rad.np(), pdf.value
+
+
+def off_axis(axis, degrees):
+    a = math.radians(degrees)
+    d = L.ora_align_to_normal(ora.v3((math.sin(a), 0.0, math.cos(a))), ora.v3(axis)).np()
+    return d / np.linalg.norm(d)
+
+
+def test_distant_light_cone_is_consistent():  # light.rs:527-566
+    d = np.array([0.3, -1.0, 0.2]) / np.linalg.norm([0.3, -1.0, 0.2])
+    l = distant(d, (2, 2, 2), 10.0)
+    rng = np.random.default_rng(7)
+    s = ora.LightSample()
+    for _ in range(2000):
+        assert L.ora_light_sample_li(C.byref(l), ora.v3((0, 0, 0)), rng.random(), rng.random(), C.byref(s))
+        assert abs(np.linalg.norm(s.direction.np()) - 1.0) < 1e-5
+        assert math.isinf(s.distance)
+        e = escaped(l, s.direction.np())
+        assert e is not None, "sample_li produced a direction escaped() does not cover"
+        assert (e[0] == s.radiance.np()).all()
+        assert abs(e[1] - s.pdf) < 1e-3 * s.pdf
+    assert escaped(l, d) is None
+    assert escaped(l, off_axis(-np.asarray(l.normal[:]), 20.0)) is None
+
+
+def test_distant_light_irradiance_is_angle_invariant():  # light.rs:576-591
+    e = np.array([3.0, 2.0, 1.0])
+    s = ora.LightSample()
+    for angle in (0.0, 0.53, 5.0, 30.0):
+        l = distant((0, -1, 0), e, angle)
+        assert L.ora_light_sample_li(C.byref(l), ora.v3((0, 0, 0)), 0.4, 0.6, C.byref(s))
+        recovered = s.radiance.np() / s.pdf
+        assert np.linalg.norm(recovered - e) < 1e-3 * np.linalg.norm(e), angle
+
+
+def test_distant_light_zero_angle_stays_finite():  # light.rs:595-612
+    l = distant((0, -1, 0), (1, 1, 1), 0.0)
+    s = ora.LightSample()
+    assert L.ora_light_sample_li(C.byref(l), ora.v3((0, 0, 0)), 0.5, 0.5, C.byref(s))
+    assert math.isfinite(s.pdf) and s.pdf > 0
+    assert np.isfinite(s.radiance.np()).all()
+    assert escaped(l, off_axis((0, 1, 0), 1.0)) is None
+
+
+def test_distant_light_has_no_geometry():  # light.rs:616-621
+    l = distant((0, -1, 0), (1, 1, 1), 1.0)
+    assert l.geom_id == 0xFFFFFFFF
+    assert L.ora_light_pdf_at_point(C.byref(l), ora.v3((0, 0, 0)), ora.v3((0, 1, 0))) == 0.0
+
+
+def test_distant_light_python_form_matches_oracle_constructor():
+    """The derived fields the importer hands to both renderers follow DistantLight::new (light.rs:255-266)."""
+    import importlib
+    usda = importlib.import_module("crust-render_amd.usda")
+    for direction, angle in (((0.3, -1.0, 0.2), 10.0), ((0, -1, 0), 0.53), ((1, 1, 1), 0.0), ((0, 0, -2), 400.0)):
+        d = usda.distant_light(direction, (1, 2, 3), angle)
+        l = distant(direction, (1, 2, 3), angle)
+        assert np.allclose(d["direction"], l.normal[:], rtol=0, atol=1.2e-7)
+        assert abs(d["cos_half_angle"] - l.radius) <= 1.2e-7
+        assert abs(d["solid_angle"] - l.center[0]) <= 1e-6 * max(l.center[0], 1e-6) + 8e-7
+    assert usda.distant_light((0, 0, 0), (1, 1, 1)) is None
+
+
+def test_uniform_dome_covers_every_direction():  # light.rs:340-390 without a map
+    l = ora.Light()
+    l.kind, l.geom_id = ora.LIGHT_DOME, 0xFFFFFFFF
+    l.radiance = (C.c_float * 3)(0.5, 0.6, 0.7)
+    rng = np.random.default_rng(3)
+    s = ora.LightSample()
+    mean = np.zeros(3)
+    for _ in range(2000):
+        assert L.ora_light_sample_li(C.byref(l), ora.v3((0, 0, 0)), rng.random(), rng.random(), C.byref(s))
+        assert abs(np.linalg.norm(s.direction.np()) - 1.0) < 1e-5 and math.isinf(s.distance)
+        assert abs(s.pdf - 1 / (4 * math.pi)) < 1e-7
+        e = escaped(l, s.direction.np())
+        assert e is not None and (e[0] == s.radiance.np()).all() and e[1] == s.pdf
+        mean += s.direction.np()
+    assert np.linalg.norm(mean / 2000) < 0.05  # uniform over the sphere
+
+
 def test_area_light_pdf_is_positive_facing_side():  # light.rs:482-521
     l = sphere_light((0, 5, 0), 1.0)
     pdf = L.ora_light_pdf_at_point(C.byref(l), ora.v3((0, 0, 0)), ora.v3((0, 4, 0)))
