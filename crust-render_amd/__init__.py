@@ -154,7 +154,7 @@ ABI_SYMBOLS = [
     "crt_builder_new", "crt_builder_free", "crt_reserve", "crt_count", "crt_attach_triangles", "crt_attach_sphere",
     "crt_attach_instance", "crt_attach_empty", "crt_set_triangles", "crt_set_sphere", "crt_set_instance", "crt_commit",
     "crt_scene_retain", "crt_scene_release", "crt_scene_bounds", "crt_scene_geometry_count", "crt_scene_has_motion",
-    "crt_scene_primitive_count", "crt_scene_primitive_breakdown", "crt_scene_memory_footprint", "crt_scene_tree",
+    "crt_scene_primitive_count", "crt_scene_primitive_breakdown", "crt_scene_unique_primitive_breakdown", "crt_scene_memory_footprint", "crt_scene_tree",
     "crt_shard_pixels", "crt_intersect1", "crt_occluded1", "crt_intersect_n", "crt_occluded_n", "crt_intersect_n_stats",
     "crt_occluded_n_stats", "crt_material_default", "crt_camera_new", "crt_renderer_new", "crt_renderer_free",
     "crt_renderer_pixel_count", "crt_renderer_pixel_indices", "crt_render_samples", "crt_film_resolve",
@@ -204,6 +204,7 @@ def lib():
     L.crt_scene_primitive_count.restype = C.c_size_t
     L.crt_scene_primitive_count.argtypes = [vp]
     L.crt_scene_primitive_breakdown.argtypes = [vp, C.POINTER(C.c_size_t)]
+    L.crt_scene_unique_primitive_breakdown.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.crt_scene_memory_footprint.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.crt_scene_tree.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                  C.POINTER(up)]
@@ -337,6 +338,12 @@ class Scene:
     def primitive_breakdown(self):
         out = (C.c_size_t * 5)()
         _check(lib().crt_scene_primitive_breakdown(self.h, out), "crt_scene_primitive_breakdown")
+        return dict(zip(("triangles", "spheres", "curve_segments", "cubic_curve_spans", "instances"), map(int, out)))
+
+    def unique_primitive_breakdown(self):
+        """Scene::unique_primitive_breakdown (scene.rs:422-427): what is resident, shared prototypes once."""
+        out = (C.c_size_t * 5)()
+        _check(lib().crt_scene_unique_primitive_breakdown(self.h, out), "crt_scene_unique_primitive_breakdown")
         return dict(zip(("triangles", "spheres", "curve_segments", "cubic_curve_spans", "instances"), map(int, out)))
 
     def memory_footprint(self):
@@ -678,10 +685,47 @@ def load_usda(path, width=None, height=None, max_depth=None, rank=0, world=1, va
     r._protos = protos
     return r, desc
 
+def render_with_report(path, spp=None, out_exr=None, width=None, height=None, max_depth=None, variance=None,
+                       batch=16):
+    """The reference binary's run in one call (main.rs:491-648): load, commit, render, optionally write the EXR, and
+    return (image, RenderStats) — the report carries the phases the reference prints ("Parse USD stage",
+    "Commit acceleration structure", "Render", "Write image") and its scene / ray statistics blocks.
+    spp / variance default to the scene's own RenderSettings (adaptive stopping on, as the binary renders)."""
+    import sys
+    from . import stats as _stats
+    st = _stats.RenderStats()
+    me = sys.modules[__name__]
+    with st.phase("Parse USD stage"):
+        desc = usda.load(path, width, height)
+    s = desc.settings
+    with st.phase("Commit acceleration structure"):
+        scene, materials, protos = usda.build_world(desc, me, default_material)
+        scene.memory_footprint()  # uploads the device image: part of the commit, not of the render
+    var = s["variance"] if variance is None else variance
+    settings = RenderSettings(s["width"], s["height"], s["max_depth"] if max_depth is None else max_depth, s["frame"],
+                              s["strategy"], s["filter"], s["filter_radius"], float(var), s["min_spp"])
+    r = Renderer(scene, materials, desc.lights, make_camera(**desc.camera), settings)
+    r._protos = protos
+    n = int(spp if spp is not None else s["spp"])
+    with st.phase("Render"):
+        if var > 0:
+            r.render_adaptive(n, batch=batch)
+        else:
+            for b in range(0, n, 32):
+                r.render_samples(b, min(32, n - b))
+        img = r.image()  # synchronises: the film read-back ends the phase
+    if out_exr:
+        with st.phase("Write image"):
+            exr.write_exr(out_exr, img[::-1])  # film buffer rows run bottom to top (buffer.rs:45-49)
+    _stats.for_render(scene, r, n, st)
+    return img, st
+
+
 load_scene = load_usda  # the same loader under the name that fits all it reads (.usda, .usd/.usdc crates, synthetic:*)
 
 from . import usda  # noqa: E402,F401  (the minimal USDA reader, SURVEY §8 f1)
 from . import usdc  # noqa: E402,F401  (the USDC crate reader, SURVEY §8 f3)
 from . import shard  # noqa: E402,F401  (pixel-tile sharding + the tile gather)
 from . import exr  # noqa: E402,F401  (EXR writer / reader + the reference's exr_diff metrics, SURVEY §8 f4)
+from . import stats  # noqa: E402,F401  (RenderStats + the reference's report layout, SURVEY §8 f4)
 from . import synthetic  # noqa: E402,F401  (scenes built in code: the labelled stand-in for BASELINE config 5)

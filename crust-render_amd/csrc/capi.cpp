@@ -4,6 +4,7 @@
 
 #include <cstring>
 #include <new>
+#include <unordered_set>
 
 #include "crt_internal.h"
 
@@ -159,6 +160,25 @@ int crt_scene_primitive_breakdown(const CrtScene *s, size_t out[5]) {
     else if (p.kind == PRIM_SPHERE) out[1]++;
     else out[4]++;
   }
+  return CRT_OK;
+}
+namespace {
+void accumulate_unique(const Scene &sc, std::unordered_set<const Scene *> &visited, size_t acc[5]) {  // bvh.rs:397-416
+  for (const Prim &p : sc.bvh.prims) {
+    if (p.kind == PRIM_TRI) acc[0]++;
+    else if (p.kind == PRIM_SPHERE) acc[1]++;
+    else {
+      acc[4]++;
+      if (visited.insert(p.scene.get()).second) accumulate_unique(*p.scene, visited, acc);
+    }
+  }
+}
+}  // namespace
+int crt_scene_unique_primitive_breakdown(const CrtScene *s, size_t out[5]) {
+  if (!s || !out) return CRT_ERR_BAD_ARG;
+  out[0] = out[1] = out[2] = out[3] = out[4] = 0;
+  std::unordered_set<const Scene *> visited;
+  accumulate_unique(*s->p, visited, out);
   return CRT_OK;
 }
 int crt_scene_memory_footprint(CrtScene *s, size_t out[6]) {

@@ -117,6 +117,9 @@ int crt_scene_has_motion(const CrtScene *s);                        /* scene.rs:
 size_t crt_scene_primitive_count(const CrtScene *s);                /* scene.rs:400 */
 /* primitive_breakdown: triangles, spheres, curve_segments, cubic_curve_spans, instances   scene.rs:409 */
 int crt_scene_primitive_breakdown(const CrtScene *s, size_t out[5]);
+/* unique_primitive_breakdown: the same five counts over what is resident in memory — instanced scenes are
+ * descended, each distinct prototype once however many placements share it             scene.rs:422-427 */
+int crt_scene_unique_primitive_breakdown(const CrtScene *s, size_t out[5]);
 /* memory_footprint: prim_nodes, boxed_prims, bvh_nodes, leaves, packets, indices (device bytes) scene.rs:459 */
 int crt_scene_memory_footprint(CrtScene *s, size_t out[6]);
 /* Host copies of the committed tree of THIS scene (local indices), for build-parity checks:

@@ -1227,6 +1227,40 @@ int ora_scene_bounds(const OraScene *s, float out[6]) {
 uint32_t ora_geometry_count(const OraScene *s) { return s->n_geoms; }
 int ora_has_motion(const OraScene *s) { return s->has_motion; }
 size_t ora_primitive_count(const OraScene *s) { return s->bvh.n_prims; }
+void ora_primitive_breakdown(const OraScene *s, size_t out[5]) { /* scene.rs:409 */
+  memset(out, 0, 5 * sizeof out[0]);
+  for (size_t i = 0; i < s->bvh.n_prims; i++) {
+    const int k = s->bvh.prims[i].kind;
+    out[k == PRIM_TRI ? 0 : k == PRIM_SPHERE ? 1 : 4]++;
+  }
+}
+/* bvh.rs:397-416: every primitive of this tree once; an instanced scene is entered the first time it is met. */
+typedef struct { const OraScene **seen; size_t n, cap; } Visited;
+static void accumulate_unique(const OraScene *s, Visited *vis, size_t acc[5]) {
+  for (size_t i = 0; i < s->bvh.n_prims; i++) {
+    const Prim *p = &s->bvh.prims[i];
+    if (p->kind == PRIM_TRI) acc[0]++;
+    else if (p->kind == PRIM_SPHERE) acc[1]++;
+    else {
+      acc[4]++;
+      int known = 0;
+      for (size_t k = 0; k < vis->n && !known; k++) known = vis->seen[k] == p->scene;
+      if (known) continue;
+      if (vis->n == vis->cap) {
+        vis->cap = vis->cap ? 2 * vis->cap : 16;
+        vis->seen = (const OraScene **)realloc((void *)vis->seen, vis->cap * sizeof *vis->seen);
+      }
+      vis->seen[vis->n++] = p->scene;
+      accumulate_unique(p->scene, vis, acc);
+    }
+  }
+}
+void ora_unique_primitive_breakdown(const OraScene *s, size_t out[5]) { /* scene.rs:422-427 */
+  Visited vis = {NULL, 0, 0};
+  memset(out, 0, 5 * sizeof out[0]);
+  accumulate_unique(s, &vis, out);
+  free((void *)vis.seen);
+}
 
 int ora_linear_scan(const OraScene *s, const OraRay *ray, float t_min, float t_max, OraRayHit *out) {
   float closest = t_max; int found = 0; OraPrimHit best;

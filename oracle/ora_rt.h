@@ -58,6 +58,9 @@ int ora_scene_bounds(const OraScene *s, float out[6]);                   /* scen
 uint32_t ora_geometry_count(const OraScene *s);                          /* scene.rs:380 */
 int ora_has_motion(const OraScene *s);                                   /* scene.rs:395 */
 size_t ora_primitive_count(const OraScene *s);                           /* scene.rs:400 */
+/* out: triangles, spheres, curve_segments, cubic_curve_spans, instances */
+void ora_primitive_breakdown(const OraScene *s, size_t out[5]);          /* scene.rs:409 */
+void ora_unique_primitive_breakdown(const OraScene *s, size_t out[5]);   /* scene.rs:422-427, bvh.rs:397-416 */
 
 /* Batched helpers for tests / cpu_baseline (rays: 8 floats o,d,time,mask-bits; hits: 8 x 4-byte
  * t,nx,ny,nz,u,v,geom,prim + front flags array). */

@@ -189,6 +189,8 @@ def lib():
     L.ora_has_motion.argtypes = [C.c_void_p]
     L.ora_primitive_count.restype = C.c_size_t
     L.ora_primitive_count.argtypes = [C.c_void_p]
+    L.ora_primitive_breakdown.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    L.ora_unique_primitive_breakdown.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
     L.ora_intersect_n.argtypes = [C.c_void_p, fp, C.c_size_t, C.c_float, C.c_float, fp, up, C.POINTER(C.c_uint8)]
     L.ora_occluded_n.argtypes = [C.c_void_p, fp, C.c_size_t, C.c_float, C.c_float, C.POINTER(C.c_uint8)]
     L.ora_set_trav_stats.argtypes = [C.POINTER(TravStats)]
@@ -357,6 +359,17 @@ class Scene:
 
     def primitive_count(self):
         return lib().ora_primitive_count(self.h)
+
+    def _breakdown(self, fn):
+        out = (C.c_size_t * 5)()
+        fn(self.h, out)
+        return dict(zip(("triangles", "spheres", "curve_segments", "cubic_curve_spans", "instances"), map(int, out)))
+
+    def primitive_breakdown(self):
+        return self._breakdown(lib().ora_primitive_breakdown)
+
+    def unique_primitive_breakdown(self):
+        return self._breakdown(lib().ora_unique_primitive_breakdown)
 
     def intersect_n(self, rays, t_min=0.001, t_max=INF):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)

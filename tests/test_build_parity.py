@@ -66,6 +66,23 @@ def test_empty_and_reserved_slots(crt):
     assert e.value.code == -2
 
 
+def test_unique_breakdown_counts_shared_prototypes_once(crt):  # scene.rs:716-748, through the C ABI
+    leaf = crt.SceneBuilder()
+    leaf.attach_sphere((0, 0, 0), 1.0)
+    leaf = leaf.commit()
+    mid = crt.SceneBuilder()
+    for x in (-2.0, 2.0):
+        mid.attach_instance(leaf, [1, 0, 0, 0, 1, 0, 0, 0, 1, x, 0, 0])
+    mid = mid.commit()
+    root = crt.SceneBuilder()
+    for y in (-5.0, 5.0):
+        root.attach_instance(mid, [1, 0, 0, 0, 1, 0, 0, 0, 1, 0, y, 0])
+    s = root.commit()
+    top, unique = s.primitive_breakdown(), s.unique_primitive_breakdown()
+    assert top["instances"] == 2 and top["spheres"] == 0
+    assert unique["spheres"] == 1 and unique["instances"] == 4
+
+
 def test_out_of_range_indices_are_skipped(crt):
     b = crt.SceneBuilder()
     b.attach_triangles([(0, 0, 0), (1, 0, 0), (0, 1, 0)], [(0, 1, 2), (0, 1, 9)])  # scene.rs:251-253

@@ -183,3 +183,22 @@ def test_fused_and_per_stage_launches_agree(crt, tmp_path):
         outs.append((np.load(path), res.stdout.strip().splitlines()[-1]))
     assert outs[0][1] == outs[1][1]
     assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
+
+
+def test_render_report_counts_the_scene_and_the_rays(crt, tmp_path):
+    """render_with_report (main.rs:491-648 in one call): the report's scene block shows cornellbox as the reference's
+    importer leaves it (822 baked triangles + 2 placements of one 760-triangle mesh), the ray block
+    equals the renderer's counters, every phase is listed, and the EXR on disk is the image returned."""
+    out = str(tmp_path / "cb.exr")
+    img, st = crt.render_with_report(os.path.join(ROOT, "scenes", "cornellbox.usda"), spp=8, out_exr=out, width=64,
+                                     height=36, variance=0.0)
+    assert st.scene.top_level.triangles == 822 and st.scene.top_level.instances == 2
+    assert st.scene.unique.triangles == 822 + 760 and st.scene.unique.instances == 2
+    assert st.image.width == 64 and st.image.samples_per_pixel == 8
+    assert st.rays.camera_rays == 64 * 36 * 8 and st.rays.total_rays() > st.rays.camera_rays
+    text = st.report()
+    for needle in ("Render Statistics", "primitives in memory", "kernel memory", "Ray Statistics", "throughput",
+                   "Parse USD stage", "Commit acceleration structure", "Render", "Write image", "Profile by time"):
+        assert needle in text, needle
+    back = crt.exr.read_exr(out)
+    assert np.array_equal(np.ascontiguousarray(back[::-1], dtype=np.float32).view(np.uint32), img.view(np.uint32))

@@ -370,6 +370,15 @@ def nested_scene():
     return root.commit()
 
 
+def test_unique_breakdown_counts_shared_prototypes_once():  # scene.rs:716-748
+    s = nested_scene()
+    top = s.primitive_breakdown()
+    assert top["instances"] == 2 and top["spheres"] == 0
+    unique = s.unique_primitive_breakdown()
+    assert unique["spheres"] == 1, "shared prototype counted more than once"
+    assert unique["instances"] == 4
+
+
 def test_instances_nest():  # scene.rs:655-710
     s = nested_scene()
     assert s.primitive_count() == 2
