@@ -106,6 +106,9 @@ def main():
     n_pix_total = args.width * args.height
     d_rgb = torch.empty(r.n_pix * 3, dtype=torch.float32, device="cuda")
     plan = crt.shard.GatherPlan(args.width, args.height, world, coll) if dist is not None else None
+    if dist is not None:  # untimed: the first collective of a kind pays the communicator's channel setup
+        r.film_to(d_rgb, stream)
+        plan.gather(d_rgb.reshape(-1, 3).to(coll), dist)
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
