@@ -224,19 +224,16 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
           const float closest = g0.w;
           if (STATS) st.nodes[level > 0 ? 1 : 0]++;
           float4 mnx, mny, mnz, mxx, mxy, mxz;
-          uint4 ch;
-          uint32_t flags;
+          uint4 ch;  // device form: leaf children tagged, empty lanes kInvalid (scene.cpp)
           if (cur < n_lds) {  // top of the tree: LDS (ds_read_b128), no trip through the vector memory pipeline
             const float4 *nb = reinterpret_cast<const float4 *>(lds_nodes + (size_t)cur * kLdsNodeStride);
             mnx = nb[0]; mny = nb[1]; mnz = nb[2]; mxx = nb[3]; mxy = nb[4]; mxz = nb[5];
             ch = *reinterpret_cast<const uint4 *>(nb + 6);
-            flags = lds_nodes[(size_t)cur * kLdsNodeStride + 28];
           } else {
             const WideNode *nd = &S.nodes[cur];
             const float4 *nb = reinterpret_cast<const float4 *>(nd);
             mnx = nb[0]; mny = nb[1]; mnz = nb[2]; mxx = nb[3]; mxy = nb[4]; mxz = nb[5];
             ch = *reinterpret_cast<const uint4 *>(nd->child);
-            flags = nd->flags;
           }
           const float lo_x[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, lo_y[4] = {mny.x, mny.y, mny.z, mny.w},
                       lo_z[4] = {mnz.x, mnz.y, mnz.z, mnz.w};
@@ -252,9 +249,8 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
             const float t0z = (lo_z[l] - g0.z) * g1.z, t1z = (hi_z[l] - g0.z) * g1.z;
             const float tn = fmaxf(fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z)), t_min);
             const float tf = fminf(fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)), closest);
-            const bool on = (tn <= tf) && ((flags >> l) & 1u);
             key[l] = tn;
-            ent[l] = on ? (child[l] | (((flags >> (4 + l)) & 1u) ? kLeafTag : 0u)) : kInvalid;  // kInvalid = lane off
+            ent[l] = (tn <= tf) ? child[l] : kInvalid;  // kInvalid = lane off (an empty lane's word already is)
           }
           // Stack image after this node, bottom to top. Ordered traversal: inner lanes far to near, then leaf
           // lanes far to near on top, so they pop first and near-first — the reference's "leaf lanes now, near

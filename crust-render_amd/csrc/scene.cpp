@@ -292,6 +292,13 @@ int Scene::ensure_device() {
       if (in.root != CRT_INVALID_ID) in.root = new_idx[in.root];
     if (me.root != CRT_INVALID_ID) me.root = new_idx[me.root];
   }
+  // Device form of a node's child words: leaf children carry the leaf tag (bit 31), empty lanes are CRT_INVALID_ID,
+  // so the traversal derives everything from the word it has to load anyway and never touches `flags`.
+  for (WideNode &n : f.nodes)
+    for (int l = 0; l < 4; l++) {
+      if (!(n.flags & (1u << l))) n.child[l] = CRT_INVALID_ID;
+      else if (n.flags & (1u << (4 + l))) n.child[l] |= 0x80000000u;
+    }
   auto img = std::make_unique<DeviceImage>();
   const size_t sz[7] = {f.nodes.size() * sizeof(WideNode), f.leaves.size() * sizeof(Leaf),
                         f.packets.size() * sizeof(Tri4),   f.indices.size() * sizeof(uint32_t),
