@@ -32,9 +32,13 @@ namespace crt {
 namespace dev {
 
 constexpr int kBlock = 256;       // threads per workgroup (4 waves)
-// Top of the tree staged in LDS: the first nodes (breadth-first numbering) as 144-byte records
-// (128 + 16 pad: a 36-dword stride spreads the lanes' 16-byte reads over all banks).
-constexpr int kLdsNodeStride = 36;  // dwords
+// Top of the tree staged in LDS: the first nodes (breadth-first numbering), bounds + child words only (112 of the
+// node's 128 bytes: the traversal does not read `flags`). Two nodes' 16-byte reads collide on banks only when
+// their indices differ by a multiple of 16, the same as with any padded stride.
+#ifndef CRT_LDS_NODE_STRIDE
+#define CRT_LDS_NODE_STRIDE 28
+#endif
+constexpr int kLdsNodeStride = CRT_LDS_NODE_STRIDE;  // dwords
 constexpr int kMaxLevels = 8;     // instance nesting depth (usd_import.rs:60 MAX_INSTANCE_NESTING)
 constexpr uint32_t kLeafTag = 0x80000000u;
 constexpr uint32_t kInvalid = 0xFFFFFFFFu;
@@ -207,8 +211,9 @@ __device__ __forceinline__ void motion_w2l(const DevInstance &in, float time, fl
 // Cooperative copy of the top-of-tree window into LDS; returns the number of nodes staged. Ends with a barrier.
 __device__ __forceinline__ uint32_t stage_nodes(const DevScene &S, uint32_t *lds_nodes, int cap) {
   const uint32_t n = S.n_nodes < (uint32_t)cap ? S.n_nodes : (uint32_t)cap;
-  for (uint32_t w = threadIdx.x; w < n * 8u; w += blockDim.x) {  // 8 x 16 bytes per node
+  for (uint32_t w = threadIdx.x; w < n * 8u; w += blockDim.x) {  // 7 of the 8 x 16 bytes of a node
     const uint32_t node = w >> 3, part = w & 7u;
+    if (part == 7u) continue;
     const float4 v = reinterpret_cast<const float4 *>(S.nodes + node)[part];
     *reinterpret_cast<float4 *>(lds_nodes + (size_t)node * kLdsNodeStride + part * 4) = v;
   }

@@ -229,6 +229,9 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
             const float4 *nb = reinterpret_cast<const float4 *>(lds_nodes + (size_t)cur * kLdsNodeStride);
             mnx = nb[0]; mny = nb[1]; mnz = nb[2]; mxx = nb[3]; mxy = nb[4]; mxz = nb[5];
             ch = *reinterpret_cast<const uint4 *>(nb + 6);
+            // Opaque to the optimiser: without it the two arms are merged into FLAT loads through a generic pointer,
+            // which serve the LDS lanes more slowly than ds_read_b128 (MedCity +1.8 %, profiles/README.md).
+            asm volatile("" : "+v"(mnx.x), "+v"(mxx.x), "+v"(ch.x));
           } else {
             const WideNode *nd = &S.nodes[cur];
             const float4 *nb = reinterpret_cast<const float4 *>(nd);
@@ -704,7 +707,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
 #define CRT_POOL_ROWS 2
 #endif
 #ifndef CRT_POOL_NODES
-#define CRT_POOL_NODES 32
+#define CRT_POOL_NODES 72
 #endif
 constexpr int kPoolNodes = CRT_POOL_NODES;  // nodes of the top of the tree staged in LDS per workgroup
 constexpr int kEngineLdsDwords = (kBlock / 64) * pool_lds_dwords<CRT_POOL_ROWS>() + kPoolNodes * kLdsNodeStride;
