@@ -61,6 +61,15 @@ __device__ __forceinline__ uint32_t ctl_phase(uint32_t c) { return (c >> 23) & 7
 // planes of R*64: ctl, cur, aux, cursor, mask; then the stack, kPoolStack planes. 60 + 4*kPoolStack bytes per ray.
 // The hit found so far (u, v, primitive, geometry) and the caller's slot tag are written once or twice per ray and
 // read at the end: they live in private memory with the other rarely used state.
+// Lanes of the wave for which p holds, as a 32-bit scalar. The empty asm hides that the value came from a 64-bit
+// population count: otherwise the comparisons below are carried out as 64-bit VECTOR compares (there is no scalar
+// ordered compare for 64 bits) with a register-pair move each, in the scheduler's every round.
+__device__ __forceinline__ int wave_count(bool p) {
+  int n = (int)__popcll(__ballot(p));
+  asm volatile("" : "+s"(n));
+  return n;
+}
+
 template <bool ANY, bool STATS, int ROWS, class Fetch, class Emit>
 __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's pool_lds_dwords<ROWS>() */, float t_min,
                               const uint32_t *lds_nodes /* staged top of the tree */, uint32_t n_lds, uint32_t &err,
@@ -148,7 +157,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
     uint32_t have = 0;  // bit q: this lane has a slot in phase q
 #pragma unroll
     for (int row = 0; row < ROWS; row++) have |= 1u << ph[row];
-    const int n_free = __popcll(__ballot(have & (1u << PH_FREE)));
+    const int n_free = wave_count(have & (1u << PH_FREE));
     if (more && n_free >= kFetchMin) {
       // ---- fetch + setup ----
       lap(0);
@@ -183,11 +192,11 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
     }
 
     // ---- pick the phase to run: a rare one once enough lanes wait for it, else the busier of node / packet ----
-    const int n_node = __popcll(__ballot(have & (1u << PH_NODE)));
-    const int n_pkt = __popcll(__ballot(have & (1u << PH_PACKET)));
-    const int n_sc = __popcll(__ballot(have & (1u << PH_SCALAR)));
-    const int n_exit = __popcll(__ballot(have & (1u << PH_EXIT)));
-    const int n_emit = __popcll(__ballot(have & (1u << PH_EMIT)));
+    const int n_node = wave_count(have & (1u << PH_NODE));
+    const int n_pkt = wave_count(have & (1u << PH_PACKET));
+    const int n_sc = wave_count(have & (1u << PH_SCALAR));
+    const int n_exit = wave_count(have & (1u << PH_EXIT));
+    const int n_emit = wave_count(have & (1u << PH_EMIT));
     uint32_t q;
     {
       int best_rare = n_sc;
@@ -326,7 +335,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
           }
           act = next == PH_NODE;
         }
-        if (__popcll(__ballot(act)) < kStickyMin) break;  // wave-uniform
+        if (wave_count(act) < kStickyMin) break;  // wave-uniform
       }
       if (mine) {
         W(W_CTL, row) = (c & ~0xffu) | sp;
@@ -458,7 +467,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
             act = false;
           }
         }
-        if (__popcll(__ballot(act)) < kStickyMin) break;  // wave-uniform
+        if (wave_count(act) < kStickyMin) break;  // wave-uniform
       }
       if (mine) {
         if (accepted) {
