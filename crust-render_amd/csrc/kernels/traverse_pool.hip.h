@@ -219,13 +219,13 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
 
     if (q == PH_NODE) {
       // ================= node expansion (bvh.rs:455-505), repeated while most of the lanes stay in it =================
-      float4 g0 = make_float4(0, 0, 0, 0), g1 = g0;
-      uint32_t c = 0, sp = 0, base = 0, level = 0, cur = 0, cursor = 0;
-      if (mine) {
-        g0 = f0[at(row)]; g1 = f1[at(row)];
-        c = W(W_CTL, row); cur = W(W_CUR, row);
-        sp = c & 0xffu; base = (c >> 8) & 0xffu; level = (c >> 16) & 7u;
-      }
+      // Every lane loads (its own slot of `row`: always addressable); lanes without a ray in this phase just
+      // carry the values along, `act` keeps them out of every effect. No zero-initialisation, no masked loads.
+      const float4 g0 = f0[at(row)], g1 = f1[at(row)];
+      const uint32_t c = W(W_CTL, row);
+      uint32_t cur = W(W_CUR, row), cursor = 0;
+      uint32_t sp = c & 0xffu;
+      const uint32_t base = (c >> 8) & 0xffu, level = (c >> 16) & 7u;
       bool act = mine;
       for (;;) {
         if (act) {
@@ -344,14 +344,12 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
       }
     } else if (q == PH_PACKET) {
       // ============ Tri4 packets of the current leaf (bvh.rs:514-562, triangle.rs:276-348), one per turn ============
-      float4 g0 = make_float4(0, 0, 0, 0), g1 = g0;
-      float2 g2 = make_float2(0, 0);
-      uint32_t c = 0, sp = 0, base = 0, level = 0, cur = 0, k = 0, aux = 0, rmask = 0;
-      if (mine) {
-        g0 = f0[at(row)]; g1 = f1[at(row)]; g2 = f2[at(row)];
-        c = W(W_CTL, row); cur = W(W_CUR, row); k = W(W_CURSOR, row); aux = W(W_AUX, row); rmask = W(W_MASK, row);
-        sp = c & 0xffu; base = (c >> 8) & 0xffu; level = (c >> 16) & 7u;
-      }
+      const float4 g0 = f0[at(row)], g1 = f1[at(row)];  // unconditional, as in the node phase
+      const float2 g2 = f2[at(row)];
+      const uint32_t c = W(W_CTL, row), rmask = W(W_MASK, row);
+      uint32_t cur = W(W_CUR, row), k = W(W_CURSOR, row), aux = W(W_AUX, row);
+      uint32_t sp = c & 0xffu;
+      const uint32_t base = (c >> 8) & 0xffu, level = (c >> 16) & 7u;
       int kx, ky, kz;
       unpack_k(c, kx, ky, kz);
       float closest = g0.w;
