@@ -28,7 +28,7 @@ namespace dev {
 #define CRT_FETCH_MIN 32
 #endif
 #ifndef CRT_RARE_MIN
-#define CRT_RARE_MIN 16
+#define CRT_RARE_MIN 24
 #endif
 constexpr int kPoolStack = CRT_POOL_STACK;   // stack entries per ray kept in LDS; deeper entries go to private memory
 constexpr int kPoolSpill = 256 - kPoolStack; // same total capacity as the one-ray-per-lane kernel
