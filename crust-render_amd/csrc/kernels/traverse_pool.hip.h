@@ -279,27 +279,24 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
             pos[0] = 0; pos[1] = on[0]; pos[2] = on[0] + on[1]; pos[3] = on[0] + on[1] + on[2];
             n_tot = pos[3] + on[3];
           } else {
-            // nr[i][j] (i < j): lane i is visited before lane j  <=>  key_i <= key_j (stable)
-            const uint32_t n01 = key[0] <= key[1], n02 = key[0] <= key[2], n03 = key[0] <= key[3];
-            const uint32_t n12 = key[1] <= key[2], n13 = key[1] <= key[3], n23 = key[2] <= key[3];
-            uint32_t in4[4];
+            // For every pair i < j: x = 1 iff lane j ends up below lane i. Same kind: the farther one is below,
+            // and lane i is the nearer one iff key_i <= key_j (stable: equal keys keep lane order, bvh.rs:472-486).
+            // Different kinds: the inner lane is below the leaf lane. Exactly one of the two is below the other, so
+            // pos_i += on_j & x and pos_j += on_i & !x; no branches, no per-kind sums.
 #pragma unroll
-            for (int i = 0; i < 4; i++) in4[i] = on[i] - lf4[i];
-            const uint32_t n_in = in4[0] + in4[1] + in4[2] + in4[3];
-            // entries of the same kind that are FARTHER than lane i sit below it
-            const uint32_t f0k[3] = {n01, n02, n03};                    // lane 0 nearer than 1, 2, 3
-            const uint32_t f1k[3] = {1u - n01, n12, n13};               // lane 1 nearer than 0, 2, 3
-            const uint32_t f2k[3] = {1u - n02, 1u - n12, n23};          // lane 2 nearer than 0, 1, 3
-            const uint32_t f3k[3] = {1u - n03, 1u - n13, 1u - n23};     // lane 3 nearer than 0, 1, 2
-            pos[0] = lf4[0] ? n_in + (f0k[0] & lf4[1]) + (f0k[1] & lf4[2]) + (f0k[2] & lf4[3])
-                            : (f0k[0] & in4[1]) + (f0k[1] & in4[2]) + (f0k[2] & in4[3]);
-            pos[1] = lf4[1] ? n_in + (f1k[0] & lf4[0]) + (f1k[1] & lf4[2]) + (f1k[2] & lf4[3])
-                            : (f1k[0] & in4[0]) + (f1k[1] & in4[2]) + (f1k[2] & in4[3]);
-            pos[2] = lf4[2] ? n_in + (f2k[0] & lf4[0]) + (f2k[1] & lf4[1]) + (f2k[2] & lf4[3])
-                            : (f2k[0] & in4[0]) + (f2k[1] & in4[1]) + (f2k[2] & in4[3]);
-            pos[3] = lf4[3] ? n_in + (f3k[0] & lf4[0]) + (f3k[1] & lf4[1]) + (f3k[2] & lf4[2])
-                            : (f3k[0] & in4[0]) + (f3k[1] & in4[1]) + (f3k[2] & in4[2]);
-            n_tot = n_in + lf4[0] + lf4[1] + lf4[2] + lf4[3];
+            for (int i = 0; i < 4; i++) pos[i] = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+#pragma unroll
+              for (int j = i + 1; j < 4; j++) {
+                const uint32_t a = key[i] <= key[j] ? 1u : 0u;
+                const uint32_t t = lf4[i] ^ lf4[j];
+                const uint32_t x = (t & lf4[i]) | (~t & a);  // v_bfi_b32
+                pos[i] += on[j] & x;
+                pos[j] += on[i] & (x ^ 1u);
+              }
+            }
+            n_tot = on[0] + on[1] + on[2] + on[3];
           }
           if (n_tot == 0) {
             next = advance(row, sp, base, level, 0, cur, cursor);
