@@ -94,6 +94,19 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
   Frame frames[ROWS][kMaxLevels];
   uint32_t spill[ROWS][kPoolSpill];
 
+  // side_d / side_n / best live in registers. Indexed by a run-time row they would be read and written through
+  // compare-and-select chains over ALL their elements (what the compiler makes of a dynamic index into a promoted
+  // array: 30 instructions per store); with the row loop unrolled each access is one select per row.
+  auto rd = [&](auto &arr, int row, int f) {
+    auto r = arr[0][f];
+#pragma unroll
+    for (int k = 1; k < ROWS; k++) r = row == k ? arr[k][f] : r;
+    return r;
+  };
+  auto wr = [&](auto &arr, int row, int f, auto val) {
+#pragma unroll
+    for (int k = 0; k < ROWS; k++) arr[k][f] = row == k ? (decltype(arr[k][f] + 0))val : arr[k][f];
+  };
   auto push = [&](int row, uint32_t &sp, uint32_t x) {
     if (sp < (uint32_t)kPoolStack) STK((int)sp, row) = x;
     else if (sp - kPoolStack < (uint32_t)kPoolSpill) spill[row][sp - kPoolStack] = x;
@@ -178,9 +191,9 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
         const uint32_t first = empty ? PH_EMIT : PH_NODE;
         W(W_CTL, row) = ctl_pack(0, 0, 0, S.has_packets ? 1u : 0u, kz, swap, 0);
         W(W_CUR, row) = S.root;
-        W(W_AUX, row) = 0; W(W_CURSOR, row) = 0; W(W_MASK, row) = in.mask; best[row][B_SLOT] = in.slot;
-        best[row][B_BU] = 0; best[row][B_BV] = 0; best[row][B_BDEFER] = kInvalid; best[row][B_BGEOM] = kInvalid;
-        side_d[row][0] = in.dx; side_d[row][1] = in.dy; side_d[row][2] = in.dz; side_d[row][3] = in.time;
+        W(W_AUX, row) = 0; W(W_CURSOR, row) = 0; W(W_MASK, row) = in.mask; wr(best, row, B_SLOT, in.slot);
+        wr(best, row, B_BU, 0); wr(best, row, B_BV, 0); wr(best, row, B_BDEFER, kInvalid); wr(best, row, B_BGEOM, kInvalid);
+        wr(side_d, row, 0, in.dx); wr(side_d, row, 1, in.dy); wr(side_d, row, 2, in.dz); wr(side_d, row, 3, in.time);
 #pragma unroll
         for (int k = 0; k < ROWS; k++)
           if (k == row) ph[k] = first;
@@ -467,7 +480,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
       if (mine) {
         if (accepted) {
           f0[at(row)].w = closest;
-          best[row][B_BU] = __float_as_uint(bu); best[row][B_BV] = __float_as_uint(bv); best[row][B_BDEFER] = bdefer;
+          wr(best, row, B_BU, __float_as_uint(bu)); wr(best, row, B_BV, __float_as_uint(bv)); wr(best, row, B_BDEFER, bdefer);
           aux |= 1u << level;
         }
         if (occluded) aux |= 1u;
@@ -497,7 +510,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
         const uint32_t rmask = W(W_MASK, row);
         uint32_t rem = (aux >> 8) & 0xffu;
         float closest = g0.w;
-        const float dx = side_d[row][0], dy = side_d[row][1], dz = side_d[row][2], time = side_d[row][3];
+        const float dx = rd(side_d, row, 0), dy = rd(side_d, row, 1), dz = rd(side_d, row, 2), time = rd(side_d, row, 3);
         const uint32_t pi = S.indices[cursor];
         cursor++;
         rem--;
@@ -528,7 +541,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
               qx = qx + w2l[6] * dz; qy = qy + w2l[7] * dz; qz = qz + w2l[8] * dz;
               RayCtx r;
               r.ox = px; r.oy = py; r.oz = pz; r.dx = qx; r.dy = qy; r.dz = qz;  // unnormalised: local t == world t
-              side_d[row][0] = qx; side_d[row][1] = qy; side_d[row][2] = qz;
+              wr(side_d, row, 0, qx); wr(side_d, row, 1, qy); wr(side_d, row, 2, qz);
               level++;
               aux &= ~(1u << level);
               base = sp;
@@ -565,11 +578,11 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
                 else {
                   closest = root;
                   f0[at(row)].w = root;
-                  side_n[row][0] = ((g0.x + root * dx) - s.x) / s.w;
-                  side_n[row][1] = ((g0.y + root * dy) - s.y) / s.w;
-                  side_n[row][2] = ((g0.z + root * dz) - s.z) / s.w;
-                  side_n[row][3] = __uint_as_float(0u);  // prim_id 0
-                  best[row][B_BU] = 0; best[row][B_BV] = 0; best[row][B_BDEFER] = kInvalid; best[row][B_BGEOM] = hd.y;
+                  wr(side_n, row, 0, ((g0.x + root * dx) - s.x) / s.w);
+                  wr(side_n, row, 1, ((g0.y + root * dy) - s.y) / s.w);
+                  wr(side_n, row, 2, ((g0.z + root * dz) - s.z) / s.w);
+                  wr(side_n, row, 3, __uint_as_float(0u));  // prim_id 0
+                  wr(best, row, B_BU, 0); wr(best, row, B_BV, 0); wr(best, row, B_BDEFER, kInvalid); wr(best, row, B_BGEOM, hd.y);
                   aux |= 1u << level;
                   if (STATS) st.accepted++;
                 }
@@ -591,7 +604,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
                 if (!(flat && __float_as_uint(p->d[9]) == kInvalid)) {
                   closest = t;
                   f0[at(row)].w = t;
-                  best[row][B_BU] = __float_as_uint(u); best[row][B_BV] = __float_as_uint(v); best[row][B_BDEFER] = pi;
+                  wr(best, row, B_BU, __float_as_uint(u)); wr(best, row, B_BV, __float_as_uint(v)); wr(best, row, B_BDEFER, pi);
                   aux |= 1u << level;
                   if (STATS) st.accepted++;
                 }
@@ -618,20 +631,20 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
         uint32_t aux = W(W_AUX, row);
         uint32_t cur = W(W_CUR, row);
         const float closest = f0[at(row)].w;
-        const float time = side_d[row][3];
+        const float time = rd(side_d, row, 3);
         const bool inner_found = (aux >> level) & 1u;
         level--;
         const Frame f = frames[row][level];
         if (inner_found) {
           float bnx, bny, bnz;
           uint32_t bprim;
-          const uint32_t bdefer = best[row][B_BDEFER];
+          const uint32_t bdefer = rd(best, row, B_BDEFER);
           if (bdefer != kInvalid) {
-            tri_normal(S, bdefer, __uint_as_float(best[row][B_BU]), __uint_as_float(best[row][B_BV]), bnx, bny, bnz);
+            tri_normal(S, bdefer, __uint_as_float(rd(best, row, B_BU)), __uint_as_float(rd(best, row, B_BV)), bnx, bny, bnz);
             bprim = S.prims[bdefer].prim_id;
           } else {
-            bnx = side_n[row][0]; bny = side_n[row][1]; bnz = side_n[row][2];
-            bprim = __float_as_uint(side_n[row][3]);
+            bnx = rd(side_n, row, 0); bny = rd(side_n, row, 1); bnz = rd(side_n, row, 2);
+            bprim = __float_as_uint(rd(side_n, row, 3));
           }
           const DevInstance *in = &S.instances[f.inst];
           float nm[9];
@@ -651,16 +664,16 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
           x = x + nm[3] * bny; y = y + nm[4] * bny; z = z + nm[5] * bny;
           x = x + nm[6] * bnz; y = y + nm[7] * bnz; z = z + nm[8] * bnz;
           const float len = sqrtf(dot3(x, y, z, x, y, z));
-          side_n[row][0] = x / len; side_n[row][1] = y / len; side_n[row][2] = z / len;
-          side_n[row][3] = __uint_as_float(bprim);
+          wr(side_n, row, 0, x / len); wr(side_n, row, 1, y / len); wr(side_n, row, 2, z / len);
+          wr(side_n, row, 3, __uint_as_float(bprim));
           // the hit is attributed to the instance's geometry id; prim_id stays the inner one
-          best[row][B_BDEFER] = kInvalid; best[row][B_BGEOM] = f.geom;
+          wr(best, row, B_BDEFER, kInvalid); wr(best, row, B_BGEOM, f.geom);
           aux |= 1u << level;
           if (STATS) st.accepted++;
         }
         RayCtx r;
         r.ox = f.ox; r.oy = f.oy; r.oz = f.oz; r.dx = f.dx; r.dy = f.dy; r.dz = f.dz;
-        side_d[row][0] = f.dx; side_d[row][1] = f.dy; side_d[row][2] = f.dz;
+        wr(side_d, row, 0, f.dx); wr(side_d, row, 1, f.dy); wr(side_d, row, 2, f.dz);
         uint32_t kz, swap;
         store_ray(row, r, f.has_packets != 0, closest, kz, swap);
         uint32_t cursor = f.cursor;
@@ -676,21 +689,21 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
       if (mine) {
         CRT_PHASE(6)
         const uint32_t aux = W(W_AUX, row);
-        const uint32_t slot = best[row][B_SLOT];
+        const uint32_t slot = rd(best, row, B_SLOT);
         const bool is_hit = (aux & 1u) != 0;
         Hit hit;
         hit.t = 0.0f; hit.u = 0.0f; hit.v = 0.0f; hit.nx = hit.ny = hit.nz = 0.0f; hit.geom = kInvalid; hit.prim = kInvalid;
         if (!ANY && is_hit) {
           hit.t = f0[at(row)].w;
-          hit.u = __uint_as_float(best[row][B_BU]); hit.v = __uint_as_float(best[row][B_BV]);
-          const uint32_t bdefer = best[row][B_BDEFER];
+          hit.u = __uint_as_float(rd(best, row, B_BU)); hit.v = __uint_as_float(rd(best, row, B_BV));
+          const uint32_t bdefer = rd(best, row, B_BDEFER);
           if (bdefer != kInvalid) {
             tri_normal(S, bdefer, hit.u, hit.v, hit.nx, hit.ny, hit.nz);
             const DevPrim *p = &S.prims[bdefer];
             hit.geom = p->geom_id; hit.prim = p->prim_id;
           } else {
-            hit.nx = side_n[row][0]; hit.ny = side_n[row][1]; hit.nz = side_n[row][2];
-            hit.geom = best[row][B_BGEOM]; hit.prim = __float_as_uint(side_n[row][3]);
+            hit.nx = rd(side_n, row, 0); hit.ny = rd(side_n, row, 1); hit.nz = rd(side_n, row, 2);
+            hit.geom = rd(best, row, B_BGEOM); hit.prim = __float_as_uint(rd(side_n, row, 3));
           }
         }
         emit(slot, is_hit, hit);
