@@ -33,6 +33,16 @@ namespace dev {
 constexpr int kPoolStack = CRT_POOL_STACK;   // stack entries per ray kept in LDS; deeper entries go to private memory
 constexpr int kPoolSpill = 256 - kPoolStack; // same total capacity as the one-ray-per-lane kernel
 constexpr int kFetchMin = CRT_FETCH_MIN;     // fetch new rays once this many lanes have a free slot
+#ifndef CRT_EMIT_BIAS
+#define CRT_EMIT_BIAS 16
+#endif
+#ifndef CRT_SCALAR_BIAS
+#define CRT_SCALAR_BIAS 0
+#endif
+#ifndef CRT_EXIT_BIAS
+#define CRT_EXIT_BIAS 0
+#endif
+constexpr int kEmitBias = CRT_EMIT_BIAS, kScalarBias = CRT_SCALAR_BIAS, kExitBias = CRT_EXIT_BIAS;
 constexpr int kRareMin = CRT_RARE_MIN;       // run a rare phase (scalar prim / instance exit / emit) at this many lanes
 #ifndef CRT_STICKY_MIN
 #define CRT_STICKY_MIN 24
@@ -212,14 +222,20 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
     const int n_emit = wave_count(have & (1u << PH_EMIT));
     uint32_t q;
     {
-      int best_rare = n_sc;
+      // emit is the cheapest rare phase and frees a slot; it triggers at kRareMin + kEmitBias waiting lanes
+      int best_rare = n_sc - kScalarBias;
       uint32_t q_rare = PH_SCALAR;
-      if (n_exit > best_rare) { best_rare = n_exit; q_rare = PH_EXIT; }
-      if (n_emit > best_rare) { best_rare = n_emit; q_rare = PH_EMIT; }
+      if (n_exit - kExitBias > best_rare) { best_rare = n_exit - kExitBias; q_rare = PH_EXIT; }
+      if (n_emit - kEmitBias > best_rare) { best_rare = n_emit - kEmitBias; q_rare = PH_EMIT; }
       if (best_rare >= kRareMin) q = q_rare;
       else if (n_node + n_pkt > 0) q = n_node >= n_pkt ? PH_NODE : PH_PACKET;
-      else if (best_rare > 0) q = q_rare;
-      else break;  // every slot is free (and the source is dry, or the fetch above would have run)
+      else {  // nothing but rare work is left: the largest group, whatever its size
+        best_rare = n_sc; q_rare = PH_SCALAR;
+        if (n_exit > best_rare) { best_rare = n_exit; q_rare = PH_EXIT; }
+        if (n_emit > best_rare) { best_rare = n_emit; q_rare = PH_EMIT; }
+        if (best_rare > 0) q = q_rare;
+        else break;  // every slot is free (and the source is dry, or the fetch above would have run)
+      }
     }
     const bool mine = (have & (1u << q)) != 0;
     int row = 0;
