@@ -25,7 +25,7 @@ namespace dev {
 #define CRT_POOL_STACK 6
 #endif
 #ifndef CRT_FETCH_MIN
-#define CRT_FETCH_MIN 32
+#define CRT_FETCH_MIN 40
 #endif
 #ifndef CRT_RARE_MIN
 #define CRT_RARE_MIN 24
@@ -42,6 +42,10 @@ constexpr int kFetchMin = CRT_FETCH_MIN;     // fetch new rays once this many la
 #ifndef CRT_EXIT_BIAS
 #define CRT_EXIT_BIAS 0
 #endif
+#ifndef CRT_PACKET_BIAS
+#define CRT_PACKET_BIAS 0
+#endif
+constexpr int kPacketBias = CRT_PACKET_BIAS;  // node steps are preferred until the packet group leads by more than this
 constexpr int kEmitBias = CRT_EMIT_BIAS, kScalarBias = CRT_SCALAR_BIAS, kExitBias = CRT_EXIT_BIAS;
 constexpr int kRareMin = CRT_RARE_MIN;       // run a rare phase (scalar prim / instance exit / emit) at this many lanes
 #ifndef CRT_STICKY_MIN
@@ -228,7 +232,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
       if (n_exit - kExitBias > best_rare) { best_rare = n_exit - kExitBias; q_rare = PH_EXIT; }
       if (n_emit - kEmitBias > best_rare) { best_rare = n_emit - kEmitBias; q_rare = PH_EMIT; }
       if (best_rare >= kRareMin) q = q_rare;
-      else if (n_node + n_pkt > 0) q = n_node >= n_pkt ? PH_NODE : PH_PACKET;
+      else if (n_node + n_pkt > 0) q = (n_node > 0 && (n_pkt == 0 || n_node + kPacketBias >= n_pkt)) ? PH_NODE : PH_PACKET;
       else {  // nothing but rare work is left: the largest group, whatever its size
         best_rare = n_sc; q_rare = PH_SCALAR;
         if (n_exit > best_rare) { best_rare = n_exit; q_rare = PH_EXIT; }
