@@ -5,9 +5,9 @@
 
 Workload (config.workload): samples/cornellbox.usda at 1920x1080, scene-default depth 32, triangle filter r=1,
 adaptive stopping off (variance 0), frame 0. A "step" is ONE wavefront batch: `--spp-per-step` samples (default
-32) of every pixel a rank owns — generate, then up to depth+1 rounds of extend / shade / shadow, then the film
-fold — with the scene, the path-state planes (11 GB at this size) and the film resident in HBM before the timed
-region starts. 1024 spp is 32 such steps; the default K is 16.
+64) of every pixel a rank owns — generate, then up to depth+1 rounds of extend / shade / shadow, then the film
+fold — with the scene, the path-state planes (22 GB at this size) and the film resident in HBM before the timed
+region starts. 1024 spp is 16 such steps, the default K.
 
 Metric (stats.rs:150-152): Mray/s = (closest_hit + shadow_rays) / render seconds / 1e6, summed
 over all ranks; the timed region is K steps bracketed by barrier + synchronize, MAX over ranks.
@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp-per-step", type=int, default=32)
+    ap.add_argument("--spp-per-step", type=int, default=64)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default="cornellbox")
