@@ -142,6 +142,7 @@ struct DevScene {
   uint32_t root;         // CRT_INVALID_ID when the scene is empty (bvh.rs:442-444)
   uint32_t has_packets;
   uint32_t n_nodes;      // nodes are numbered breadth-first, top-level tree first (see Scene::ensure_device)
+  uint32_t pool_stack;   // LDS stack entries per ray the traversal engine uses for this scene (6 flat, 10 instanced)
 };
 
 struct DeviceImage {

@@ -30,8 +30,14 @@ namespace dev {
 #ifndef CRT_RARE_MIN
 #define CRT_RARE_MIN 24
 #endif
-constexpr int kPoolStack = CRT_POOL_STACK;   // stack entries per ray kept in LDS; deeper entries go to private memory
-constexpr int kPoolSpill = 256 - kPoolStack; // same total capacity as the one-ray-per-lane kernel
+// Stack entries per ray kept in LDS (deeper entries go to private memory) and nodes of the top of the tree staged in
+// LDS are two sides of one LDS budget, and the best split depends on the scene: a single-level scene rarely goes
+// deeper than six entries and profits from the node window; instance-heavy scenes stack the parent's entries under
+// the instance's and run +6 % with ten entries and next to no window (profiles/README.md). The host picks the split
+// per scene (DevScene::pool_stack); both fit the same arena.
+constexpr int kPoolStack = CRT_POOL_STACK;       // flat scenes
+constexpr int kPoolStackDeep = 10;               // instance-heavy scenes
+constexpr int kPoolSpill = 256 - kPoolStack;     // private part: same total capacity as the one-ray-per-lane kernel
 constexpr int kFetchMin = CRT_FETCH_MIN;     // fetch new rays once this many lanes have a free slot
 #ifndef CRT_EMIT_BIAS
 #define CRT_EMIT_BIAS 16
@@ -55,7 +61,7 @@ constexpr int kStickyMin = CRT_STICKY_MIN;   // keep repeating node / packet ste
 
 // LDS dwords one wave needs for ROWS rays per lane.
 template <int ROWS>
-constexpr int pool_lds_dwords() { return (4 + 4 + 2 + 5 + kPoolStack) * ROWS * 64; }
+constexpr int pool_lds_dwords(int stack) { return (4 + 4 + 2 + 5 + stack) * ROWS * 64; }
 
 enum : uint32_t { PH_FREE = 0, PH_NODE = 1, PH_PACKET = 2, PH_SCALAR = 3, PH_EXIT = 4, PH_EMIT = 5 };
 
@@ -86,8 +92,8 @@ __device__ __forceinline__ int wave_count(bool p) {
 
 template <bool ANY, bool STATS, int ROWS, class Fetch, class Emit>
 __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's pool_lds_dwords<ROWS>() */, float t_min,
-                              const uint32_t *lds_nodes /* staged top of the tree */, uint32_t n_lds, uint32_t &err,
-                              LaneStats &st, Fetch fetch, Emit emit) {
+                              const uint32_t *lds_nodes /* staged top of the tree */, uint32_t n_lds, uint32_t pstack,
+                              uint32_t &err, LaneStats &st, Fetch fetch, Emit emit) {
   const int lane = threadIdx.x & 63;
   constexpr int RL = ROWS * 64;
   float4 *f0 = reinterpret_cast<float4 *>(lds);
@@ -122,14 +128,14 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
     for (int k = 0; k < ROWS; k++) arr[k][f] = row == k ? (decltype(arr[k][f] + 0))val : arr[k][f];
   };
   auto push = [&](int row, uint32_t &sp, uint32_t x) {
-    if (sp < (uint32_t)kPoolStack) STK((int)sp, row) = x;
-    else if (sp - kPoolStack < (uint32_t)kPoolSpill) spill[row][sp - kPoolStack] = x;
+    if (sp < pstack) STK((int)sp, row) = x;
+    else if (sp - pstack < (uint32_t)kPoolSpill) spill[row][sp - pstack] = x;
     else { err |= 1u; return; }
     sp++;
   };
   auto pop = [&](int row, uint32_t &sp) -> uint32_t {
     sp--;
-    return sp < (uint32_t)kPoolStack ? STK((int)sp, row) : spill[row][sp - kPoolStack];
+    return sp < pstack ? STK((int)sp, row) : spill[row][sp - pstack];
   };
   // What the ray does next: the rest of the leaf's scalar list, else the next stack entry, else leave the tree.
   auto advance = [&](int row, uint32_t &sp, uint32_t base, uint32_t level, uint32_t rem, uint32_t &cur,
@@ -335,7 +341,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
             next = advance(row, sp, base, level, 0, cur, cursor);
           } else {
             uint32_t top_e = 0;
-            if (sp + n_tot - 1 <= (uint32_t)kPoolStack) {  // the stored entries fit the LDS part of the stack
+            if (sp + n_tot - 1 <= pstack) {  // the stored entries fit the LDS part of the stack
 #pragma unroll
               for (int i = 0; i < 4; i++) {
                 if (on[i]) {
@@ -746,17 +752,24 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
 #ifndef CRT_POOL_NODES
 #define CRT_POOL_NODES 72
 #endif
-constexpr int kPoolNodes = CRT_POOL_NODES;  // nodes of the top of the tree staged in LDS per workgroup
-constexpr int kEngineLdsDwords = (kBlock / 64) * pool_lds_dwords<CRT_POOL_ROWS>() + kPoolNodes * kLdsNodeStride;
+constexpr int kPoolNodes = CRT_POOL_NODES;  // nodes of the top of the tree staged in LDS per workgroup (flat scenes)
+constexpr int kPoolNodesDeep = 2;           // ... with the deep stack
+constexpr int kEngineLdsFlat = (kBlock / 64) * pool_lds_dwords<CRT_POOL_ROWS>(kPoolStack) + kPoolNodes * kLdsNodeStride;
+constexpr int kEngineLdsDeep = (kBlock / 64) * pool_lds_dwords<CRT_POOL_ROWS>(kPoolStackDeep) + kPoolNodesDeep * kLdsNodeStride;
+constexpr int kEngineLdsDwords = kEngineLdsFlat > kEngineLdsDeep ? kEngineLdsFlat : kEngineLdsDeep;
 // Runs the traversal for one workgroup. `lds` = kEngineLdsDwords dwords, 16-byte aligned. Contains a workgroup
 // barrier: call from uniform control flow, after the shared variables the callbacks use are initialised.
 template <bool ANY, bool STATS, class Fetch, class Emit>
 __device__ __forceinline__ void run_traversal(const DevScene &S, uint32_t *lds, float t_min, uint32_t &err, LaneStats &st,
                                               Fetch fetch, Emit emit) {
-  uint32_t *lds_nodes = lds + (kBlock / 64) * pool_lds_dwords<CRT_POOL_ROWS>();
-  const uint32_t n_lds = stage_nodes(S, lds_nodes, kPoolNodes);  // ends with a barrier
-  traverse_pool<ANY, STATS, CRT_POOL_ROWS>(S, lds + (threadIdx.x >> 6) * pool_lds_dwords<CRT_POOL_ROWS>(), t_min, lds_nodes,
-                                           n_lds, err, st, fetch, emit);
+  // the split of the arena is the scene's (uniform): clamp to what the arena was sized for
+  const uint32_t pstack = S.pool_stack >= (uint32_t)kPoolStackDeep ? (uint32_t)kPoolStackDeep : (uint32_t)kPoolStack;
+  const int pnodes = pstack == (uint32_t)kPoolStackDeep ? kPoolNodesDeep : kPoolNodes;
+  const int wave_dwords = pool_lds_dwords<CRT_POOL_ROWS>((int)pstack);
+  uint32_t *lds_nodes = lds + (kBlock / 64) * wave_dwords;
+  const uint32_t n_lds = stage_nodes(S, lds_nodes, pnodes);  // ends with a barrier
+  traverse_pool<ANY, STATS, CRT_POOL_ROWS>(S, lds + (threadIdx.x >> 6) * wave_dwords, t_min, lds_nodes, n_lds, pstack, err,
+                                           st, fetch, emit);
 }
 
 }  // namespace dev

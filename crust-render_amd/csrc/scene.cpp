@@ -11,6 +11,7 @@
 #include <cstring>
 #include <unordered_map>
 
+#include <cstdlib>
 #include "crt_internal.h"
 
 namespace crt {
@@ -328,6 +329,10 @@ int Scene::ensure_device() {
   img->view.root = me.root;
   img->view.has_packets = me.has_packets;
   img->view.n_nodes = uint32_t(f.nodes.size());
+  // kernels/traverse_pool.hip.h: the engine's LDS split. Deep stacks pay where rays spend their time inside
+  // instances (thousands of placements); a handful of placements under a real top-level tree is still a flat scene.
+  img->view.pool_stack = f.instances.size() >= 64 ? 10u : 6u;
+  if (const char *e = getenv("CRT_POOL_STACK_RT")) img->view.pool_stack = (uint32_t)atoi(e);  // A/B runs
   dev = std::move(img);
   return CRT_OK;
 }
