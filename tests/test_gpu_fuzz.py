@@ -73,3 +73,33 @@ def test_random_world_renders_identically(crt, seed):
     assert np.isfinite(oimg).all()
     bad = np.argwhere(img.view(np.uint32) != oimg.view(np.uint32))
     assert bad.shape[0] == 0, (seed, bad.shape[0], bad[:3])
+
+
+@pytest.mark.parametrize("split", ["6", "10"])
+def test_both_lds_splits_of_the_engine_match_the_oracle(crt, split, monkeypatch):
+    """The traversal engine divides its LDS between stack entries and the node window per scene (6 + 72 nodes, or
+    10 + 2 for instance-heavy scenes, scene.cpp). Forcing each split (CRT_POOL_STACK_RT, read when the device image
+    is built) over scenes with nested instances: hits and occlusion flags identical to the oracle."""
+    import torch
+    monkeypatch.setenv("CRT_POOL_STACK_RT", split)
+    for seed in (13, 16, 18):
+        recipe = fuzz_scenes.recipe(seed)
+        o_scene, _ok = fuzz_scenes.build(ora, recipe)
+        p_scene, _pk = fuzz_scenes.build(crt, recipe)
+        rng = np.random.default_rng(77 + seed)
+        n = 4000
+        rays = np.zeros((n, 8), dtype=np.float32)
+        rays[:, 0:3] = rng.uniform(-9, 9, (n, 3)).astype(np.float32)
+        rays[:, 3:6] = (rng.uniform(-5, 5, (n, 3)) - rays[:, 0:3]).astype(np.float32)
+        rays[:, 6] = rng.choice(np.array([0.0, 0.5, 1.0], dtype=np.float32), n)
+        rays[:, 7] = np.full(n, 0xFFFFFFFF, np.uint32).view(np.float32)
+        d_rays = crt.rays_to_device(rays)
+        hf, ids, _front = o_scene.intersect_n(rays, 0.001, float("inf"))
+        occ = o_scene.occluded_n(rays, 0.001, float("inf"))
+        hits = crt.hits_to_host(p_scene.intersect_n(d_rays, 0.001, float("inf")))
+        got_occ = p_scene.occluded_n(d_rays, 0.001, float("inf"))
+        torch.cuda.synchronize()
+        hit = ids[:, 0] != 0xFFFFFFFF
+        assert np.array_equal(hits["geom_id"], ids[:, 0]) and np.array_equal(hits["prim_id"], ids[:, 1])
+        assert np.array_equal(hits["t"][hit].view(np.uint32), hf[hit, 0].view(np.uint32))
+        assert np.array_equal(got_occ.cpu().numpy().astype(np.uint8), occ)
