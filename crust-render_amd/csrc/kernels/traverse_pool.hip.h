@@ -417,6 +417,11 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
               r.ox = g0.x; r.oy = g0.y; r.oz = g0.z;
               r.kx = kx; r.ky = ky; r.kz = kz; r.sx = g1.w; r.sy = g2.x; r.sz = g2.y;
               r.okx = sel3(g0.x, g0.y, g0.z, kx); r.oky = sel3(g0.x, g0.y, g0.z, ky); r.okz = sel3(g0.x, g0.y, g0.z, kz);
+              // primitive ids and the normal-ok bits ride along with the vertex loads: fetched at the point of use they
+              // would be up to four more dependent round trips per packet, one per accepted lane
+              const uint4 prim4 = *reinterpret_cast<const uint4 *>(pk->prim);
+              const uint32_t normal_ok = pk->normal_ok;
+              const uint32_t prim_of[4] = {prim4.x, prim4.y, prim4.z, prim4.w};
               const float4 *pl = reinterpret_cast<const float4 *>(&pk->v[0][0][0]);
               const float4 A_x = pl[0 + kx], A_y = pl[0 + ky], A_z = pl[0 + kz];
               const float4 B_x = pl[3 + kx], B_y = pl[3 + ky], B_z = pl[3 + kz];
@@ -462,9 +467,9 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
                 for (int l = 0; l < 4; l++) {  // bvh.rs:533-550
                   if (!((hits >> l) & 1u)) continue;
                   if (ht[l] > closest) continue;               // strict: an exact tie goes to the later lane
-                  if (!((pk->normal_ok >> l) & 1u)) continue;  // prim.rs:81-83 degenerate sliver
+                  if (!((normal_ok >> l) & 1u)) continue;  // prim.rs:81-83 degenerate sliver
                   closest = ht[l]; bu = hu[l]; bv = hv[l];
-                  bdefer = pk->prim[l];
+                  bdefer = prim_of[l];
                   accepted = true;
                   if (STATS) st.accepted++;
                 }
@@ -473,14 +478,14 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
 #pragma unroll
                 for (int l = 0; l < 4; l++) {
                   if (!((fallback >> l) & 1u)) continue;
-                  const uint32_t pi = pk->prim[l];
+                  const uint32_t pi = prim_of[l];
                   const DevPrim *p = &S.prims[pi];
                   if ((rmask & p->mask) == 0) continue;
                   CRT_PHASE(7)
                   float t, u, v;
                   if (!tri_scalar(r, p->d, t_min, closest, t, u, v)) continue;
                   if (ANY) { occluded = true; break; }
-                  if (!((pk->normal_ok >> l) & 1u)) continue;
+                  if (!((normal_ok >> l) & 1u)) continue;
                   closest = t; bu = u; bv = v; bdefer = pi;
                   accepted = true;
                   if (STATS) st.accepted++;
