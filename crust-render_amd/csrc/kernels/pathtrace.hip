@@ -328,10 +328,9 @@ __device__ __forceinline__ void extend_segment(const Params &P, const PathSoA &S
     in.mask = mask; in.t_min = 0.001f; in.t_max = CRT_INF; in.slot = i;
     return true;
   };
-  auto emit = [&](uint32_t i, bool hit, const Hit &h) {
+  auto emit = [&](uint32_t i, bool hit, const Hit &h, float dx, float dy, float dz) {
     if (hit) {
-      const float4 A = S.a[i], B = S.b[i];
-      const bool front = dot3(A.w, B.x, B.y, h.nx, h.ny, h.nz) < 0.0f;  // scene.rs:356-359
+      const bool front = dot3(dx, dy, dz, h.nx, h.ny, h.nz) < 0.0f;  // scene.rs:356-359
       H.h[i] = make_float4(h.t, front ? h.nx : -h.nx, front ? h.ny : -h.ny, front ? h.nz : -h.nz);
       H.geom[i] = h.geom | (front ? 0x80000000u : 0u);
     } else {
@@ -679,7 +678,7 @@ __device__ __forceinline__ void shadow_segment(const Params &P, const PathSoA &N
     in.time = B.w; in.mask = CRT_MASK_SHADOW; in.t_min = 0.001f; in.t_max = A.w; in.slot = q;
     return true;
   };
-  auto emit = [&](uint32_t q, bool occ, const Hit &) {
+  auto emit = [&](uint32_t q, bool occ, const Hit &, float, float, float) {
     done++;
     if (occ) return;
     const float4 Cc = Q.c[q];

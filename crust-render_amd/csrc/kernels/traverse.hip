@@ -48,12 +48,11 @@ __global__ __launch_bounds__(kBlock) void intersect_n_kernel(DevScene S, const C
     in.time = tm.x; in.mask = __float_as_uint(tm.y); in.t_min = t_min; in.t_max = t_max; in.slot = k;
     return true;
   };
-  auto emit = [&](uint32_t k, bool hit, const Hit &h) {
+  auto emit = [&](uint32_t k, bool hit, const Hit &h, float dx, float dy, float dz) {
     const size_t i = ck.first + k;
     CrtRayHit out;
     if (hit) {  // scene.rs:355-365
-      const float4 d = reinterpret_cast<const float4 *>(rays + i)[1];
-      const bool front = dot3(d.x, d.y, d.z, h.nx, h.ny, h.nz) < 0.0f;
+      const bool front = dot3(dx, dy, dz, h.nx, h.ny, h.nz) < 0.0f;
       out.t = h.t;
       out.normal[0] = front ? h.nx : -h.nx;
       out.normal[1] = front ? h.ny : -h.ny;
@@ -92,7 +91,7 @@ __global__ __launch_bounds__(kBlock) void occluded_n_kernel(DevScene S, const Cr
     in.time = tm.x; in.mask = __float_as_uint(tm.y); in.t_min = t_min; in.t_max = t_max; in.slot = k;
     return true;
   };
-  auto emit = [&](uint32_t k, bool occ, const Hit &) {
+  auto emit = [&](uint32_t k, bool occ, const Hit &, float, float, float) {
     out[ck.first + k] = occ ? 1u : 0u;
     done++;
   };

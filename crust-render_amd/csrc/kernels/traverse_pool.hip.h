@@ -737,7 +737,9 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
             hit.geom = rd(best, row, B_BGEOM); hit.prim = __float_as_uint(rd(side_n, row, 3));
           }
         }
-        emit(slot, is_hit, hit);
+        // the ray's own direction: back in side_d once every instance frame has been left (closest-hit rays only
+        // finish at level 0), so the caller need not load it again to orient the normal
+        emit(slot, is_hit, hit, rd(side_d, row, 0), rd(side_d, row, 1), rd(side_d, row, 2));
         next = PH_FREE;
       }
     }
