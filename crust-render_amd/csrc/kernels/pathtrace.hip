@@ -394,12 +394,15 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
         const uint32_t i_c = bin_slot(k_c, pre, P.seg_cap);
         const uint4 D = S.d[i_c];
         const uint32_t hg = H.geom[i_c];
+        // the escaped arm's operands are requested together with the classification's (one memory round trip, not
+        // two); for a path that hit something they are loaded again by the vertex step, from L2
+        float4 A = S.a[i_c], B = S.b[i_c], Cc = S.c[i_c];
+        asm volatile("" : "+v"(A.x), "+v"(B.x), "+v"(Cc.x));
         const int remaining = (int)(D.z >> 16);
         const bool carries_medium = MEDIA && (D.w >> kMediumShift) != 0;
         if (!INF && hg == kInvalid && remaining > 0 && !carries_medium) {
           // tracer.rs:1321-1342: the path ends on the sky gradient. (With lights at infinity — INF — escaped rays
           // take the full vertex step instead: their background is a loop over the light list.)
-          const float4 A = S.a[i_c], B = S.b[i_c], Cc = S.c[i_c];
           const V3 rd = v3(A.w, B.x, B.y), beta = v3(B.z, B.w, Cc.x);
           V3 L = v3(Cc.y, Cc.z, Cc.w);
           s_closest++;
