@@ -127,6 +127,7 @@ struct Params {
   DevScene scene;
   uint32_t sample_begin;
   const CrtMaterial *materials;
+  uint32_t n_materials;
   const DevMedium *media;          // per geom_id: the material's interior medium (present == 0: none)
   const DevMedium *media_by_id;    // the present ones, by compact id - 1
   const CrtLight *lights;
@@ -241,6 +242,8 @@ __global__ void k_build_media(const CrtMaterial *materials, uint32_t n, DevMediu
 // Every stage body below is a device function working on the calling workgroup's own queue segment, with its big
 // LDS buffer passed in: the per-stage kernels hand it their own array, the fused kernel (k_path) one shared arena.
 constexpr int kArenaDwords = kEngineLdsDwords > kSobolLdsWords ? kEngineLdsDwords : kSobolLdsWords;
+static_assert(sizeof(CrtMaterial) % 4 == 0, "material records are copied as dwords");
+constexpr int kMatLdsMax = (kArenaDwords - kSobolLdsWords) / (int)(sizeof(CrtMaterial) / 4);  // materials that fit beside the Sobol tables
 
 __device__ __forceinline__ void generate_segment(const Params &P, const PathSoA &S, Counters *C, uint32_t sample_begin,
                                                  uint32_t n_samples, uint32_t *sobol_tab /* kSobolLdsWords */) {
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_extend(Params P, P
 template <bool MEDIA, bool INF>
 __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S, const PathSoA &N, const HitSoA &H,
                                               const ShadowSoA &Q, Counters *C, int cur, float4 *staging,
-                                              uint32_t *sobol_tab /* kSobolLdsWords */) {
+                                              uint32_t *sobol_tab /* kArenaDwords: Sobol tables, then the material table */) {
   __shared__ uint32_t lds_ctr[10];  // [1] shadow requests, [2..8] statistics
   __shared__ uint32_t out_n[kBins];  // survivors per direction bin
   __shared__ uint32_t pre[kBins + 1];
@@ -369,6 +372,18 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
   if (threadIdx.x < 10) lds_ctr[threadIdx.x] = 0;
   if (threadIdx.x < kBins) out_n[threadIdx.x] = 0;
   sobol_tables_init(sobol_tab);  // ends with a workgroup barrier
+  // The vertex code reads its material record a field at a time, where each lobe needs it: two dozen dependent
+  // round trips to L2 per vertex. A table that fits the rest of the arena is staged in LDS once per call instead
+  // (generic pointer: the reads become FLAT loads served by LDS); larger tables stay in global memory.
+  const CrtMaterial *mats = P.materials;
+  if (P.n_materials <= (uint32_t)kMatLdsMax) {
+    uint32_t *dst = sobol_tab + kSobolLdsWords;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(P.materials);
+    const uint32_t words = P.n_materials * (uint32_t)(sizeof(CrtMaterial) / 4);
+    for (uint32_t w = threadIdx.x; w < words; w += kBlock) dst[w] = src[w];
+    mats = reinterpret_cast<const CrtMaterial *>(dst);
+    __syncthreads();
+  }
   const uint32_t seg0 = blockIdx.x * P.seg_cap;  // shadow queue: one unbinned segment per workgroup
   uint32_t s_closest = 0, s_shadow = 0, s_vertices = 0, s_rr_t = 0, s_rr_k = 0, s_esc = 0, s_depth = 0;
   // Two kinds of work per path: a ray that escaped just adds the sky and ends (cheap), everything else runs the full
@@ -484,7 +499,7 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
         if (prev_valid) {
           s_closest++;
           if (has_hit) {
-            const CrtMaterial &mat = P.materials[geom];
+            const CrtMaterial &mat = mats[geom];
             const float cos_o = fabs_(dot(normalize(rd), rec.normal));
             V3 emitted = mat_emitted_directional(mat, cos_o);
             if (len2(emitted) > 0.0f) {
@@ -533,7 +548,7 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
                                     : splat(0.0f) + sky_gradient(unit_direction);
           L = L + beta * background;
         } else {
-          const CrtMaterial &mat = P.materials[geom];
+          const CrtMaterial &mat = mats[geom];
           // tracer.rs:1352-1361: a scattering medium already paid e^{-sigma_bar t} through the free-flight
           // competition, only the chromatic correction remains; a clear one keeps pure Beer-Lambert.
           V3 atten = splat(1.0f);
@@ -657,7 +672,7 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
 template <bool MEDIA, bool INF>
 __global__ __launch_bounds__(kBlock, CRT_SHADE_WAVES) void k_shade(Params P, PathSoA S, PathSoA N, HitSoA H, ShadowSoA Q, Counters *C,
                                                   int cur, float4 *staging) {
-  __shared__ uint32_t sobol_tab[kSobolLdsWords];
+  __shared__ uint32_t sobol_tab[kArenaDwords];
   shade_segment<MEDIA, INF>(P, S, N, H, Q, C, cur, staging, sobol_tab);
 }
 
@@ -1055,6 +1070,7 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
   Params &P = r.P;
   P.scene = scene->p->dev->view;
   P.n_lights = (uint32_t)n_lights;
+  P.n_materials = (uint32_t)n_materials;
   P.has_inf_lights = 0;
   for (size_t k = 0; k < n_lights; k++) {
     if (lights[k].kind > CRT_LIGHT_DOME) return nullptr;
