@@ -111,11 +111,13 @@ def write_exr(path, img, compression=NO_COMPRESSION):
 
 
 def read_exr(path):
-    """-> [height, width, 3] float32 (R, G, B), row 0 = top. Single-part scanline files only."""
+    """-> [height, width, 3] float32 (R, G, B), row 0 = top. Single-part files: scanline blocks, or single-level
+    tiles (the layout of the reference's own samples/sky_env.exr: 64x64 tiles, RLE, written by the `exr` crate)."""
     buf = open(path, "rb").read()
     magic, version = struct.unpack_from("<ii", buf, 0)
-    if magic != MAGIC or (version & 0xff) != 2 or (version & 0x1a00):
-        raise ValueError("not a single-part scanline OpenEXR file: %s" % path)
+    if magic != MAGIC or (version & 0xff) != 2 or (version & 0x1800):
+        raise ValueError("not a single-part OpenEXR file: %s" % path)
+    tiled = bool(version & 0x200)
     pos, attrs = 8, {}
     while buf[pos] != 0:
         e = buf.index(b"\0", pos); name = buf[pos:e].decode(); pos = e + 1
@@ -135,11 +137,31 @@ def read_exr(path):
         if (xs, ys) != (1, 1) or ptype not in (HALF, FLOAT):
             raise ValueError("unsupported channel %s" % name)
         chans.append((name, ptype))
+    planes = {n: np.zeros((h, w), dtype=np.float32) for n, _ in chans}
+    if tiled:
+        tw, th, mode = struct.unpack("<IIB", attrs["tiles"][1])
+        if mode & 0xf:
+            raise ValueError("mip / rip mapped EXR tiles are not supported")
+        nx, ny = (w + tw - 1) // tw, (h + th - 1) // th
+        for off in struct.unpack_from("<%dQ" % (nx * ny), buf, pos):
+            tx, ty, lx, ly, size = struct.unpack_from("<5i", buf, off)
+            data = buf[off + 20:off + 20 + size]
+            cols, rows = min(tw, w - tx * tw), min(th, h - ty * th)
+            expected = rows * sum(cols * (2 if t == HALF else 4) for _, t in chans)
+            if size != expected:
+                packed = _rle_decode(data, expected) if comp == RLE else zlib.decompress(data)
+                data = _predict_interleave_decode(packed)
+            q = 0
+            for r in range(rows):
+                for name, t in chans:
+                    planes[name][ty * th + r, tx * tw:tx * tw + cols] = np.frombuffer(
+                        data, dtype=np.float16 if t == HALF else np.float32, count=cols, offset=q)
+                    q += cols * (2 if t == HALF else 4)
+        return np.stack([planes.get(k, np.zeros((h, w), np.float32)) for k in ("R", "G", "B")], axis=-1)
     line_bytes = sum(w * (2 if t == HALF else 4) for _, t in chans)
     lines = _LINES[comp]
     n_blocks = (h + lines - 1) // lines
     offs = struct.unpack_from("<%dQ" % n_blocks, buf, pos)
-    planes = {n: np.zeros((h, w), dtype=np.float32) for n, _ in chans}
     for off in offs:
         y, size = struct.unpack_from("<ii", buf, off)
         data = buf[off + 8:off + 8 + size]

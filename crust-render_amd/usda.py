@@ -40,7 +40,7 @@ class Prim:
         return self.attrs.get(name, default)
 
 
-_TOKEN = re.compile(r'''\s*(?:(\#[^\n]*)|("""(?:.|\n)*?""")|("(?:[^"\\]|\\.)*")|(<[^>]*>)|([\[\](){}=,])|([^\s\[\](){}=,"<>]+))''')
+_TOKEN = re.compile(r'''\s*(?:(\#[^\n]*)|("""(?:.|\n)*?""")|("(?:[^"\\]|\\.)*")|(<[^>]*>)|([\[\](){}=,;])|(@[^@]*@)|([^\s\[\](){}=,;"<>]+))''')
 
 
 def _tokens(text):
@@ -55,7 +55,7 @@ def _tokens(text):
         pos = m.end()
         if m.group(1) is not None:
             continue
-        for k, kind in ((2, "str"), (3, "str"), (4, "path"), (5, "punct"), (6, "word")):
+        for k, kind in ((2, "str"), (3, "str"), (4, "path"), (5, "punct"), (6, "asset"), (7, "word")):
             if m.group(k) is not None:
                 out.append((kind, m.group(k)))
                 break
@@ -109,9 +109,22 @@ class _Parser:
                     self.next()
             self.expect(")")
             return tuple(items)
+        if v == "{":  # dictionary-valued metadata (customData, assetInfo): typed entries `type name = value`
+            d = {}
+            while self.peek()[1] != "}":
+                words = []
+                while self.peek()[1] not in ("=", "}", None):
+                    words.append(self.next()[1])
+                if self.peek()[1] == "=":
+                    self.next()
+                    d[words[-1] if words else ""] = self.value()
+                while self.peek()[1] in (",", ";"):
+                    self.next()
+            self.expect("}")
+            return d
         if k == "str":
-            return v.strip('"')
-        if k == "path":
+            return v[3:-3] if v.startswith('"""') else v.strip('"')
+        if k in ("path", "asset"):
             return v[1:-1]
         if v in ("true", "True"):
             return True
@@ -122,19 +135,28 @@ class _Parser:
         except ValueError:
             return float(v)
 
-    def layer_meta(self):
+    def metadata(self):
+        """A ( ... ) metadata block as a dict: `key = value` entries separated by newlines or `;`, list-op
+        qualifiers (prepend / append / add / delete / reorder) dropped, bare doc strings skipped."""
         meta = {}
         if self.peek()[1] == "(":
             self.next()
             while self.peek()[1] != ")":
                 k, v = self.next()
-                if k == "str":  # a bare doc string
+                if v is None:
+                    raise ValueError("usda: unbalanced metadata")
+                if k == "str" or v == ";":  # a bare doc string / separator
                     continue
+                words = [v]
+                while self.peek()[0] == "word" and self.peek()[1] is not None:
+                    words.append(self.next()[1])
                 if self.peek()[1] == "=":
                     self.next()
-                    meta[v] = self.value()
+                    meta[words[-1]] = self.value()
             self.expect(")")
         return meta
+
+    layer_meta = metadata
 
     def prims(self, closing=None):
         out = []
@@ -155,8 +177,7 @@ class _Parser:
         else:
             type_name, name = v, self.next()[1].strip('"')
         p = Prim(spec, type_name, name)
-        if self.peek()[1] == "(":
-            self.skip_parens()
+        p.meta = self.metadata()  # instanceable / references / active / apiSchemas / kind
         self.expect("{")
         while self.peek()[1] != "}":
             k, v = self.peek()
@@ -217,6 +238,11 @@ def _mul(a, b):
         col = (col + a[:, 3] * b[3, j]).astype(np.float32)
         out[:, j] = col
     return out
+
+
+def _det4(m):
+    """Determinant of an affine Mat4 (last row 0 0 0 1) = det of its 3x3, evaluated in double."""
+    return np.linalg.det(np.asarray(m, dtype=np.float64)[0:3, 0:3])
 
 
 def _translation(v):
@@ -524,15 +550,56 @@ def load(path, width=None, height=None):
             desc.protos.append(dict(verts=slots[slot]["verts"], idx=slots[slot]["idx"]))
         return proto_of_slot[slot]
 
-    def collect_proto_parts(root):
+    MAX_INSTANCE_NESTING = 8  # usd_import.rs:1347
+
+    def is_active(prim):
+        return prim.meta.get("active", True) is not False and prim.attr("active", True) is not False
+
+    def ref_target(prim):
+        """The internal reference a prim composes (`references = </Path>`), as a prim, or None. Only same-layer
+        references are resolved: that is all the sample stages author."""
+        ref = prim.meta.get("references")
+        if isinstance(ref, (list, tuple)):
+            ref = ref[0] if ref else None
+        return by_path.get(ref) if isinstance(ref, str) and ref else None
+
+    def is_instance(prim):
+        """Prim::is_instance: `instanceable = true` together with a composition arc (usd_import.rs:165-170)."""
+        return prim.meta.get("instanceable") is True and ref_target(prim) is not None
+
+    def composed_children(prim):
+        """The referenced prim's children come first (weaker opinions), then the prim's own."""
+        tgt = ref_target(prim)
+        return (list(tgt.children) if tgt is not None else []) + list(prim.children)
+
+    proto_cache = {}
+
+    def prototype_parts(root, depth):
+        """prototype_parts (usd_import.rs:1808-1830): a prototype's parts, built once per path."""
+        if root is None:
+            return []
+        if root.path not in proto_cache:
+            proto_cache[root.path] = collect_proto_parts(root, depth)
+        return proto_cache[root.path]
+
+    def collect_proto_parts(root, depth=0):
         """collect_proto_parts (usd_import.rs:1379-1545): the leaf geometries under a prototype root, each with its
         root-relative placement, material and mask. The root's own transform is excluded; class prims are kept."""
-        parts, stack = [], [(root, _m4())]
+        parts = []
+        if depth > MAX_INSTANCE_NESTING:
+            return parts
+        stack = [(root, _m4())]
         while stack:
             prim, parent_local = stack.pop()
-            if prim.attr("active", True) is False:
+            if not is_active(prim):
                 continue
             this_local = _m4() if prim is root else _mul(parent_local, local_matrix(prim))
+            if prim is not root and is_instance(prim):
+                # a natively-instanced prim inside a prototype is unreadable upstream and skipped with a warning
+                # (usd_import.rs:1435-1443, pinned by usd_scene.rs nested_native_instance_degrades_gracefully)
+                import warnings
+                warnings.warn(f"nested native instance at {prim.path} skipped")
+                continue
             if prim.type == "Mesh":
                 mat = _material_of(prim, by_path)
                 slot = intern_mesh(prim, mat)
@@ -546,28 +613,58 @@ def load(path, width=None, height=None):
                 parts.append(dict(proto=sphere_protos[key], local=this_local, material=_material_of(prim, by_path),
                                   mask=_ray_mask(prim)))
             elif prim.type == "PointInstancer":
-                raise NotImplementedError("usd: a PointInstancer nested inside a prototype (usd_import.rs:1547-1630)")
-            for c in prim.children:
+                parts.extend(nested_instancer_parts(prim, this_local, _ray_mask(prim), depth + 1))
+                continue  # its prototypes are reached through it, never drawn directly
+            for c in composed_children(prim):
                 stack.append((c, this_local))
         return parts
 
-    def emit_point_instancer(prim, world_xf):
-        """emit_point_instancer / read_instancer (usd_import.rs:1702-1876): translate * orient * scale per instance,
-        composed under the instancer's world transform; orientationsf wins over orientations (half);
-        invisibleIds prunes by ids (the array index where ids is absent)."""
+    def nested_instancer_parts(prim, local, mask, depth):
+        """nested_instancer_parts (usd_import.rs:1549-1606): a PointInstancer inside a prototype becomes one part per
+        prototype-part of the nested instancer, each a committed sub-scene holding that part once per placement."""
+        layout = read_instancer(prim)
+        if layout is None:
+            return []
+        targets, placements = layout
+        out = []
+        for k, target in enumerate(targets):
+            for part in prototype_parts(by_path.get(target), depth):
+                inst = []
+                for kk, xf in placements:
+                    if kk != k:
+                        continue
+                    m = _mul(xf, part["local"])
+                    if abs(float(_det4(m))) < 1e-12:
+                        continue
+                    inst.append(dict(proto=part["proto"], l2w=affine12(m), mask=part["mask"]))
+                if not inst:
+                    continue
+                desc.protos.append(dict(instances=inst))
+                out.append(dict(proto=len(desc.protos) - 1, local=local, material=part["material"], mask=mask))
+        return out
+
+    def read_instancer(prim):
+        """read_instancer (usd_import.rs:1702-1792): translate * orient * scale per instance; orientationsf wins over
+        orientations (half); invisibleIds prunes by ids (the array index where ids is absent). Returns
+        (targets, [(index into targets, instancer-relative Mat4)])."""
         targets = prim.rels.get("prototypes") or []
+        if isinstance(targets, str):
+            targets = [targets]
         proto_indices = prim.attr("protoIndices")
         if not len(targets) or proto_indices is None:
-            return
+            return None
         proto_indices = np.asarray(proto_indices).reshape(-1)
         positions = np.asarray(prim.attr("positions") if prim.attr("positions") is not None else np.zeros((0, 3)), dtype=np.float32).reshape(-1, 3)
         scales = prim.attr("scales")
         scales = None if scales is None else np.asarray(scales, dtype=np.float32).reshape(-1, 3)
         quats = prim.attr("orientationsf") if prim.attr("orientationsf") is not None else prim.attr("orientations")
-        quats = None if quats is None else np.asarray(quats, dtype=np.float32).reshape(-1, 4)  # memory order x, y, z, w
+        if quats is not None:
+            quats = np.asarray(quats, dtype=np.float32).reshape(-1, 4)
+            if not getattr(prim, "quats_xyzw", False):
+                quats = quats[:, [1, 2, 3, 0]]  # text form is (w, x, y, z); the crate stores x, y, z, w
         ids = prim.attr("ids")
         invisible = set(int(x) for x in (prim.attr("invisibleIds") if prim.attr("invisibleIds") is not None else []))
-        parts_of = {}
+        placements = []
         for i, k in enumerate(proto_indices):
             if i >= positions.shape[0]:
                 break
@@ -577,40 +674,72 @@ def load(path, width=None, height=None):
             k = int(k)
             if k < 0 or k >= len(targets):
                 continue
-            if k not in parts_of:
-                root = by_path.get(targets[k])
-                parts_of[k] = collect_proto_parts(root) if root is not None else []
             sc = scales[i] if (scales is not None and i < scales.shape[0]) else np.ones(3, dtype=np.float32)
             q = quats[i] if (quats is not None and i < quats.shape[0]) else np.array([0, 0, 0, 1], dtype=np.float32)
-            xf = _mul(world_xf, _from_scale_rotation_translation(sc, q, positions[i]))
-            for part in parts_of[k]:
-                m = _mul(xf, part["local"])
-                if abs(float(np.linalg.det(m.astype(np.float64)))) < 1e-12:
-                    continue  # attach_proto_parts: a zero scale hides an instance
-                desc.geoms.append(dict(kind="instance", proto=part["proto"], l2w=affine12(m), mask=part["mask"],
-                                       material=part["material"], name=prim.name))
+            placements.append((k, _from_scale_rotation_translation(sc, q, positions[i])))
+        return list(targets), placements
+
+    def attach_proto_parts(parts, placement, name):
+        """attach_proto_parts (usd_import.rs:1637-1671): one instance per part; non-invertible placements skipped."""
+        for part in parts:
+            m = _mul(placement, part["local"])
+            if abs(float(_det4(m))) < 1e-12:
+                continue  # a zero scale hides an instance
+            desc.geoms.append(dict(kind="instance", proto=part["proto"], l2w=affine12(m), mask=part["mask"],
+                                   material=part["material"], name=name))
+
+    def emit_point_instancer(prim, world_xf):
+        """emit_point_instancer (usd_import.rs:1832-1876): every placement attaches its prototype's parts, composed
+        under the instancer's world transform."""
+        layout = read_instancer(prim)
+        if layout is None:
+            return
+        targets, placements = layout
+        parts_of = [prototype_parts(by_path.get(t), 0) for t in targets]
+        for k, xf in placements:
+            attach_proto_parts(parts_of[k], _mul(world_xf, xf), prim.name)
 
     def visit(prim, parent_world):
         """Returns the prim's world matrix, or None when its subtree is not traversed."""
         local = local_matrix(prim)
         world = _mul(parent_world, local)
         t = prim.type
+        if is_instance(prim):  # emit_native_instance (usd_import.rs:165-189, :1616-1631): never descend into the proxy subtree
+            attach_proto_parts(prototype_parts(ref_target(prim), 0), world, prim.name)
+            return None
         if t == "PointInstancer":
             emit_point_instancer(prim, world)
             return None  # prototypes are drawn through the instancer, never on their own (usd_import.rs:205-207)
-        if t == "Mesh":
+        if t == "Mesh":  # emit_mesh (usd_import.rs:912-1003)
             mat = _material_of(prim, by_path)
+            motion = prim.attr("crust:motion:translate")
+            if abs(float(_det4(world))) < 1e-12:  # non-invertible placement: baked on the spot, motion ignored
+                pts, counts, idx = prim.attr("points"), prim.attr("faceVertexCounts"), prim.attr("faceVertexIndices")
+                if pts is not None and counts is not None and idx is not None:
+                    pts = np.asarray(pts, dtype=np.float32).reshape(-1, 3)
+                    tris = _triangulate(np.asarray(counts), np.asarray(idx), pts.shape[0])
+                    if tris.shape[0]:
+                        desc.geoms.append(dict(kind="mesh", verts=_xf_point(world, pts), idx=tris, mask=_ray_mask(prim),
+                                               material=mat, name=prim.name))
+                return world
             slot = intern_mesh(prim, mat)
             if slot is not None:
                 slots[slot]["n_place"] += 1
                 gid = len(desc.geoms)
                 desc.geoms.append(dict(kind="pending", mask=_ray_mask(prim), material=mat, name=prim.name))
-                pending.append((gid, slot, world))
-        elif t == "Sphere":
+                pending.append((gid, slot, world, motion))
+        elif t == "Sphere":  # emit_sphere (usd_import.rs:1235-1271)
             radius = f32(prim.attr("radius", 1.0))
             center = _xf_point(world, [(0.0, 0.0, 0.0)])[0]
-            desc.geoms.append(dict(kind="sphere", center=center, radius=radius, mask=_ray_mask(prim),
-                                   material=_material_of(prim, by_path), name=prim.name))
+            motion = prim.attr("crust:motion:translate")
+            if motion is not None:  # a moving sphere rides an identity-placed instance whose end transform is the shutter translation
+                desc.protos.append(dict(radius=float(radius), center=center))
+                desc.geoms.append(dict(kind="instance", proto=len(desc.protos) - 1, l2w=affine12(_m4()),
+                                       l2w_end=affine12(_translation(motion)), mask=_ray_mask(prim),
+                                       material=_material_of(prim, by_path), name=prim.name))
+            else:
+                desc.geoms.append(dict(kind="sphere", center=center, radius=radius, mask=_ray_mask(prim),
+                                       material=_material_of(prim, by_path), name=prim.name))
         elif t == "Camera":
             if desc.camera is None:
                 desc.camera = _camera(prim, world, s)
@@ -654,12 +783,12 @@ def load(path, width=None, height=None):
         stack = [(p, root_world) for p in root_prims]
         while stack:
             prim, parent_world = stack.pop()
-            if prim.spec == "class" or prim.attr("active", True) is False:
+            if prim.spec == "class" or not is_active(prim):
                 continue
             world = visit(prim, parent_world)
             if world is None:
                 continue
-            for c in prim.children:
+            for c in composed_children(prim):
                 stack.append((c, world))
 
     identity = _m4()
@@ -679,11 +808,11 @@ def load(path, width=None, height=None):
                 traverse([ch], identity)
 
     # flush_meshes (usd_import.rs:1034-1089): sole placement -> baked into world space; else instanced
-    for gid, slot, world in pending:
+    for gid, slot, world, motion in pending:
         sl = slots[slot]
         g = desc.geoms[gid]
         m3 = world[0:3, 0:3].astype(np.float64)
-        if sl["n_place"] == 1 and not sl["committed"]:
+        if sl["n_place"] == 1 and not sl["committed"] and motion is None:
             idx = sl["idx"].copy()
             if np.linalg.det(m3) < 0.0:  # bake_indices: mirrored placement swaps the winding
                 idx[:, [1, 2]] = idx[:, [2, 1]]
@@ -693,6 +822,8 @@ def load(path, width=None, height=None):
                 proto_of_slot[slot] = len(desc.protos)
                 desc.protos.append(dict(verts=sl["verts"], idx=sl["idx"]))
             g.update(kind="instance", proto=proto_of_slot[slot], l2w=affine12(world))
+            if motion is not None:  # transform_end = from_translation(v) * l2w
+                g["l2w_end"] = affine12(_mul(_translation(motion), world))
     if desc.camera is None:
         raise ValueError("usda: stage has no Camera prim")
     return desc
@@ -742,7 +873,10 @@ def build_world(desc, api, new_material):
     for p in desc.protos:  # MeshArena::committed_scene, usd_import.rs:891-909; local sphere parts :1462-1484
         b = api.SceneBuilder()
         if "radius" in p:
-            b.attach_sphere((0.0, 0.0, 0.0), float(p["radius"]))
+            b.attach_sphere(p.get("center", (0.0, 0.0, 0.0)), float(p["radius"]))
+        elif "instances" in p:  # a nested instancer's sub-scene: earlier protos placed once per nested instance
+            for it in p["instances"]:
+                b.attach_instance(protos[it["proto"]], it["l2w"], None, mask=it["mask"])
         else:
             b.attach_triangles(p["verts"], p["idx"])
         protos.append(b.commit())
@@ -754,7 +888,7 @@ def build_world(desc, api, new_material):
         elif g["kind"] == "sphere":
             b.attach_sphere(g["center"], float(g["radius"]), mask=g["mask"])
         elif g["kind"] == "instance":
-            b.attach_instance(protos[g["proto"]], g["l2w"], None, mask=g["mask"])
+            b.attach_instance(protos[g["proto"]], g["l2w"], g.get("l2w_end"), mask=g["mask"])
         else:
             b.attach_empty(mask=g["mask"])
         materials.append(fill_material(new_material(), g["material"]))

@@ -369,7 +369,8 @@ def parse(data):
         f = c.fields_of(by_path[path])
         spec = {0: "def", 1: "over", 2: "class"}[c.value(f["specifier"])] if "specifier" in f else "over"
         prim = Prim(spec, c.value(f["typeName"]) if "typeName" in f else "", path.rsplit("/", 1)[1])
-        for key in ("active", "kind"):
+        prim.quats_xyzw = True  # crate quaternions are stored imaginary part first; the text form is (w, x, y, z)
+        for key in ("active", "kind", "instanceable"):
             if key in f:
                 prim.meta[key] = c.value(f[key])
         if "active" in f:

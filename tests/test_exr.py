@@ -40,3 +40,29 @@ def test_diff_metrics(crt):
     r = crt.exr.diff(a, b)
     assert r["differing_pixels"] == 2 and r["max_abs"] == 0.5
     assert abs(r["max_rel"] - 0.5 / 1.5) < 1e-7 and abs(r["mean_abs"] - 0.75 / 18) < 1e-9
+
+
+def test_reads_the_reference_sample_environment_map(crt):
+    """samples/sky_env.exr (the lat-long HDRI samples/domelight.usda:25 binds; written by the reference's `exr` crate as
+    a single-part TILED file: 64x64 tiles, RLE, f32 B/G/R): header decodes to 128x64, every pixel is finite, and the
+    content is what the stage's doc string describes — a blue sky over a darker ground with "a small very bright sun
+    disc"."""
+    import os
+    from conftest import ROOT
+    img = crt.exr.read_exr(os.path.join(ROOT, "scenes", "sky_env.exr"))
+    assert img.shape == (64, 128, 3) and img.dtype == np.float32
+    assert np.isfinite(img).all() and (img >= 0).all()
+    top, bottom = img[0].mean(axis=0), img[-1].mean(axis=0)
+    assert top[2] > top[0] and top[2] > bottom[2]          # sky: blue dominates, brighter than the ground
+    assert bottom[0] > bottom[2]                            # ground: warm
+    sun = img.max(axis=-1) > 100.0
+    assert 0 < sun.sum() < 0.01 * sun.size                  # a small disc ...
+    assert img.max() >= 400.0                               # ... far above the sky's ~1
+    ys = np.nonzero(sun)[0]
+    assert ys.max() < 32                                    # above the horizon (row 0 = zenith)
+    # and it survives this module's writer: scanline ZIP round trip, bit for bit
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "sky.exr")
+        crt.exr.write_exr(p, img, compression=3)
+        assert np.array_equal(crt.exr.read_exr(p).view(np.uint32), img.view(np.uint32))
