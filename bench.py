@@ -47,11 +47,19 @@ def main():
     ap.add_argument("--scene", default="cornellbox")
     ap.add_argument("--depth", type=int, default=None, help="override max depth (default: the scene's, 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=128, help="spp of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-spp", type=int, default=48, help="spp of the bounded CPU-baseline sample (per run)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = this box's share: min(affinity, 16 per GPU))")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1; gloo (CPU tensors, ranks may share a GPU) rehearses the N > 1 path on a 1-GPU box")
+    ap.add_argument("--cpu-reps", type=int, default=3, help="the CPU baseline is the best of this many runs (BASELINE.md §3: min of 3)")
+    ap.add_argument("--dump-frame", default=None, help="rank 0 writes the gathered frame ([height*width, 3] float32, .npy) here")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU) and relay rank 0's
+        # line. Nothing in this process has touched the GPU yet (no torch import, no HIP call), and the launcher is a
+        # CHILD process whose exit code we return — never an exec.
+        raise SystemExit(_self_launch(args.gpus))
 
     import numpy as np
     import torch
@@ -61,8 +69,6 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 through torch.distributed.run (one process per GPU)")
         args.gpus = world
     n_dev = max(torch.cuda.device_count(), 1)
     if args.backend == "nccl" and local_rank >= n_dev:
@@ -108,16 +114,20 @@ def main():
     plan = crt.shard.GatherPlan(args.width, args.height, world, coll) if dist is not None else None
     if dist is not None:  # untimed: the first collective of a kind pays the communicator's channel setup
         r.film_to(d_rgb, stream)
-        plan.gather(d_rgb.reshape(-1, 3).to(coll), dist)
+        plan.gather(d_rgb.reshape(-1, 3).to(coll), dist, dst=0)
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         r.render_samples(k * spp_step, spp_step, stream)
     r.film_to(d_rgb, stream)
-    if dist is not None:  # the one data-path collective: gather the tile buffers (padded to the largest shard)
-        frame = plan.gather(d_rgb.reshape(-1, 3).to(coll), dist)
+    frame = None
+    if dist is not None:  # the one data-path collective: gather the tile buffers (padded to the largest shard) to rank 0
+        frame = plan.gather(d_rgb.reshape(-1, 3).to(coll), dist, dst=0)
     barrier()
     elapsed = time.perf_counter() - t0
+    if args.dump_frame and rank == 0:
+        full = frame if frame is not None else crt.shard.GatherPlan(args.width, args.height, 1, "cuda").gather(d_rgb.reshape(-1, 3))
+        np.save(args.dump_frame, full.cpu().numpy())
     st = r.stats()
     prof = r.profile_read()
     r.profile(False)
@@ -219,7 +229,7 @@ def main():
             "mean_path_length": round(rays[3] / max(rays[2], 1), 3),
             "seconds": round(elapsed, 4),
             "spp_per_second": round(args.steps * spp_step / elapsed, 2),
-            "sharding": ("16x16 pixel tiles round-robin over ranks; one %s all_gather of tile buffers" % ("RCCL" if args.backend == "nccl" else "gloo (rehearsal)")) if world > 1 else "none",
+            "sharding": ("16x16 pixel tiles round-robin over ranks; one %s gather of tile buffers to rank 0" % ("RCCL" if args.backend == "nccl" else "gloo (rehearsal)")) if world > 1 else "none",
         },
         "roofline": roofline,
         "cpu_baseline": cpu,
@@ -227,6 +237,29 @@ def main():
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _self_launch(n):
+    """Starts `python -m torch.distributed.run --nproc-per-node n bench.py <same flags>` as a child process, relays
+    its stderr, prints rank 0's single JSON line, returns the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this image
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    lines = [l for l in res.stdout.splitlines() if l.lstrip().startswith("{")]
+    for l in res.stdout.splitlines():
+        if l not in lines and l.strip():
+            print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1])
+    return res.returncode if res.returncode else (0 if lines else 1)
 
 
 def _traffic_from_profile(fused):
@@ -252,9 +285,12 @@ def _cpu_baseline(crt, desc, args):
         avail = os.cpu_count() or 1
     cores = args.cpu_threads if args.cpu_threads > 0 else min(avail, 16)  # a 1-GPU box's CPU share is 16 cores
     o = ora_world.OracleRenderer(desc, crt.usda, max_depth=args.depth, forward=0)
-    t0 = time.perf_counter()
-    _, st = o.render(args.cpu_spp, threads=cores)
-    dt = time.perf_counter() - t0
+    times = []
+    for _ in range(max(args.cpu_reps, 1)):  # min of N render-phase times (scripts/bench_scenes.sh:33 convention)
+        t0 = time.perf_counter()
+        _, st = o.render(args.cpu_spp, threads=cores)
+        times.append(time.perf_counter() - t0)
+    dt = min(times)
     model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -269,8 +305,8 @@ def _cpu_baseline(crt, desc, args):
         "unit": "Mray/s",
         "cores": cores,
         "kind": "port",
-        "sample": "%dx%d full frame at %d spp (%d rays, %.1f s), reference-order estimator, host: %s" % (
-            args.width, args.height, args.cpu_spp, st.total_rays(), dt, model),
+        "sample": "%dx%d full frame at %d spp (%d rays), best of %d runs (%s s), reference-order estimator, host: %s" % (
+            args.width, args.height, args.cpu_spp, st.total_rays(), len(times), " / ".join("%.1f" % t for t in times), model),
     }
 
 

@@ -3,8 +3,8 @@
 Every pixel is independent (per-pixel sampler keys, per-pixel film estimator: tracer.rs:543, :559-560, :599-634),
 and the reference already renders 16x16 tiles independently (tracer.rs:424-459). So the frame shards by tile with
 the scene replicated, ranks never exchange anything while tracing, and the only collective is a gather of the
-finished tile buffers: one all_gather of equal-size padded buffers (RCCL over xGMI with backend "nccl"; gloo in
-the CPU tests). Ownership is disjoint, so the assembled frame equals the single-rank frame bit for bit.
+finished tile buffers: equal-size padded buffers, gathered to rank 0 (bench.py) or to every rank (all_gather) —
+RCCL over xGMI with backend "nccl"; gloo in the CPU tests. Ownership is disjoint, so the assembled frame equals the single-rank frame bit for bit.
 """
 import ctypes as C
 
@@ -41,12 +41,21 @@ class GatherPlan:
         self.recv = torch.empty(world * self.n_max * 3, dtype=torch.float32, device=device) if world > 1 else self.send
         self.frame = torch.zeros(height * width, 3, dtype=torch.float32, device=device)
 
-    def gather(self, film_local, dist=None):
-        """film_local: [n_owned, 3] of this rank (same device as the plan). ONE all_gather_into_tensor, then one
-        indexed store per rank's shard. Returns the full frame [height*width, 3] (buffer order: row 0 = bottom)."""
+    def gather(self, film_local, dist=None, dst=None):
+        """film_local: [n_owned, 3] of this rank (same device as the plan). ONE collective, then one indexed store
+        per rank's shard. dst=None: all_gather_into_tensor, every rank gets the frame. dst=r: a gather to rank r
+        only (1/N of the bytes; RCCL runs it as N-1 point-to-point transfers over xGMI) — the other ranks return
+        None. Returns the full frame [height*width, 3] (buffer order: row 0 = bottom)."""
         self.send[: film_local.numel()] = film_local.reshape(-1)
         if self.world > 1 and dist is not None:
-            dist.all_gather_into_tensor(self.recv, self.send)
+            if dst is None:
+                dist.all_gather_into_tensor(self.recv, self.send)
+            else:
+                mine = dist.get_rank() == dst
+                parts = list(self.recv.reshape(self.world, -1).unbind(0)) if mine else None
+                dist.gather(self.send, parts, dst=dst)
+                if not mine:
+                    return None
         recv = self.recv.reshape(self.world, self.n_max, 3)
         for r in range(self.world):
             self.frame[self.idx[r]] = recv[r, : self.idx[r].numel()]

@@ -424,3 +424,45 @@ void ora_render(const OraRenderJob *job, float *rgb, OraRayStats *stats, int n_t
   if (stats) *stats = total;
   free(ws); free(th);
 }
+
+/* A list of pixels (linear buffer indices j*width+i), n_threads workers taking 64-pixel chunks: rgb[3*k] is the
+ * mean of pixel idx[k], exactly what ora_render writes at that pixel. For frames too large to render whole in a
+ * test (3840x2160 at the bench's 64 spp): per-pixel independence (tracer.rs:543, :559-560) makes any subset exact. */
+typedef struct {
+  const OraRenderJob *job; const uint32_t *idx; size_t n; float *rgb; OraRayStats stats;
+  size_t *next; pthread_mutex_t *mu;
+} PixWorker;
+
+static void *pix_worker_main(void *arg) {
+  PixWorker *w = (PixWorker *)arg;
+  VertexRec *records = (VertexRec *)malloc(sizeof(VertexRec) * ORA_MAX_RECORDS);
+  for (;;) {
+    pthread_mutex_lock(w->mu);
+    size_t k0 = *w->next;
+    *w->next = k0 + 64;
+    pthread_mutex_unlock(w->mu);
+    if (k0 >= w->n) break;
+    size_t k1 = k0 + 64 < w->n ? k0 + 64 : w->n;
+    for (size_t k = k0; k < k1; k++)
+      render_pixel(w->job, w->idx[k] % w->job->width, w->idx[k] / w->job->width, records, w->rgb + 3 * k, &w->stats);
+  }
+  free(records);
+  return NULL;
+}
+
+void ora_render_pixels(const OraRenderJob *job, const uint32_t *idx, size_t n, float *rgb, OraRayStats *stats,
+                       int n_threads) {
+  if (n_threads < 1) n_threads = 1;
+  size_t next = 0;
+  pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+  PixWorker *ws = (PixWorker *)calloc((size_t)n_threads, sizeof(PixWorker));
+  pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
+  for (int k = 0; k < n_threads; k++) {
+    ws[k].job = job; ws[k].idx = idx; ws[k].n = n; ws[k].rgb = rgb; ws[k].next = &next; ws[k].mu = &mu;
+    pthread_create(&th[k], NULL, pix_worker_main, &ws[k]);
+  }
+  OraRayStats total; memset(&total, 0, sizeof total);
+  for (int k = 0; k < n_threads; k++) { pthread_join(th[k], NULL); stats_merge(&total, &ws[k].stats); }
+  if (stats) *stats = total;
+  free(ws); free(th);
+}

@@ -40,6 +40,9 @@ typedef struct {
  * row j is the reference's Buffer row j, j = 0 at the bottom of the image, buffer.rs:45-49).
  * n_threads workers take 16x16 tiles (tracer.rs:424). */
 void ora_render(const OraRenderJob *job, float *rgb, OraRayStats *stats, int n_threads);
+/* The pixels idx[0..n) (linear buffer indices j*width+i): rgb[3k..3k+3) = what ora_render writes at idx[k]. */
+void ora_render_pixels(const OraRenderJob *job, const uint32_t *idx, size_t n, float *rgb, OraRayStats *stats,
+                       int n_threads);
 /* One pixel (tracer.rs:515-636); returns the mean and the number of samples taken. */
 uint32_t ora_render_pixel(const OraRenderJob *job, uint32_t i, uint32_t j, float rgb[3], OraRayStats *stats);
 /* One camera sample of one pixel: radiance before the filter weight (tracer.rs:559-598). */

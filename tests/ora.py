@@ -296,6 +296,7 @@ def lib():
     L.ora_filter_sample.argtypes = [C.c_int, C.c_float, C.c_float, fp, fp]
     # integrator
     L.ora_render.argtypes = [C.POINTER(RenderJob), fp, C.POINTER(RayStats), C.c_int]
+    L.ora_render_pixels.argtypes = [C.POINTER(RenderJob), C.POINTER(C.c_uint32), C.c_size_t, fp, C.POINTER(RayStats), C.c_int]
     L.ora_render_pixel.restype = C.c_uint32
     L.ora_render_pixel.argtypes = [C.POINTER(RenderJob), C.c_uint32, C.c_uint32, fp, C.POINTER(RayStats)]
     L.ora_render_sample.argtypes = [C.POINTER(RenderJob), C.c_uint32, C.c_uint32, C.c_uint32, fp,

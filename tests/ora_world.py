@@ -71,3 +71,15 @@ class OracleRenderer:
         st = ora.RayStats()
         ora.lib().ora_render(C.byref(self.job), ora._fp(img), C.byref(st), threads or (os.cpu_count() or 1))
         return img, st
+
+    def render_pixels(self, idx, spp, threads=None, forward=None):
+        """The pixels idx (linear buffer indices j*width+i) only -> ([n, 3] means, RayStats over those pixels)."""
+        if forward is not None:
+            self.job.forward = forward
+        self.job.spp = spp
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        out = np.zeros((idx.size, 3), dtype=np.float32)
+        st = ora.RayStats()
+        ora.lib().ora_render_pixels(C.byref(self.job), idx.ctypes.data_as(C.POINTER(C.c_uint32)), idx.size, ora._fp(out),
+                                    C.byref(st), threads or (os.cpu_count() or 1))
+        return out, st

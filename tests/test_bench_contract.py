@@ -47,3 +47,32 @@ def test_auxiliary_benchmarks_run():
     for e in d["scenes"].values():
         for q in ("intersect", "occluded"):
             assert e[q]["gpu_mray_s"] > 0 and e[q]["hits"] > 0 and e[q]["oracle_1t_mray_s"] > 0
+
+
+@pytest.mark.gpu
+def test_plain_invocation_with_gpus_2_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` from a plain shell (no launcher, no WORLD_SIZE) starts two ranks itself and prints
+    ONE line with n_gpus == 2; the gathered frame is bit-identical to the --gpus 1 frame of the same total spp.
+    (gloo rehearsal: the two ranks share this box's one GPU; the driver's 8-GPU run takes the same path with RCCL.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    common = ["--warmup", "1", "--width", "192", "--height", "108", "--no-cpu-baseline"]
+    f2, f1 = str(tmp_path / "f2.npy"), str(tmp_path / "f1.npy")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2",
+                          "--spp-per-step", "4", "--dump-frame", f2] + common, capture_output=True, text=True, timeout=900,
+                         cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d2 = json.loads(lines[0])
+    assert d2["n_gpus"] == 2 and d2["scaling"] == "weak" and d2["value"] > 0
+    assert "gather" in d2["config"]["sharding"] and d2["config"]["spp_per_step"] == 8
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--spp-per-step", "8",
+                          "--dump-frame", f1] + common, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d1 = json.loads([l for l in res.stdout.splitlines() if l.strip()][0])
+    assert d1["n_gpus"] == 1
+    import numpy as np
+    a, b = np.load(f1), np.load(f2)
+    assert a.shape == (192 * 108, 3) and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    # the same rays were traced either way (stats.rs:150-152 counters, summed over ranks)
+    assert d1["config"]["rays_total"] == d2["config"]["rays_total"]
