@@ -160,6 +160,7 @@ ABI_SYMBOLS = [
     "crt_renderer_pixel_count", "crt_renderer_pixel_indices", "crt_render_samples", "crt_film_resolve",
     "crt_film_read", "crt_film_clear", "crt_renderer_active_pixels", "crt_renderer_sample_counts", "crt_render_stats", "crt_renderer_profile", "crt_renderer_profile_read",
     "crt_render_samples_stats", "crt_version", "crt_last_error", "crt_device_info",
+    "crt_scene_primitive_extents", "crt_scene_traversal_error", "crt_thread_release",
 ]
 
 _lib = None
@@ -204,6 +205,9 @@ def lib():
     L.crt_scene_primitive_count.restype = C.c_size_t
     L.crt_scene_primitive_count.argtypes = [vp]
     L.crt_scene_primitive_breakdown.argtypes = [vp, C.POINTER(C.c_size_t)]
+    L.crt_scene_primitive_extents.argtypes = [vp, C.POINTER(C.c_size_t), fp, fp, fp]
+    L.crt_scene_traversal_error.argtypes = [vp, vp]
+    L.crt_thread_release.restype = None
     L.crt_scene_unique_primitive_breakdown.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.crt_scene_memory_footprint.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.crt_scene_tree.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
@@ -303,7 +307,7 @@ class Scene:
 
     def __init__(self, handle, keep=()):
         if not handle:
-            raise RuntimeError("crt_commit failed")
+            raise RuntimeError("crt_commit failed: " + lib().crt_last_error().decode())
         self.h = handle
         self._keep = list(keep)
 
@@ -339,6 +343,18 @@ class Scene:
         out = (C.c_size_t * 5)()
         _check(lib().crt_scene_primitive_breakdown(self.h, out), "crt_scene_primitive_breakdown")
         return dict(zip(("triangles", "spheres", "curve_segments", "cubic_curve_spans", "instances"), map(int, out)))
+
+    def primitive_extents(self):
+        """Scene::primitive_extents (scene.rs:446-455) -> (count, scene diagonal, mean, max primitive diagonal)."""
+        n, d, mean, mx = C.c_size_t(), C.c_float(), C.c_float(), C.c_float()
+        _check(lib().crt_scene_primitive_extents(self.h, C.byref(n), C.byref(d), C.byref(mean), C.byref(mx)),
+               "crt_scene_primitive_extents")
+        return n.value, d.value, mean.value, mx.value
+
+    def traversal_error(self, stream=None):
+        """Drains `stream`, reads and clears the scene's traversal error word: raises CrtError(CRT_ERR_STACK) if a
+        batched launch since the last call overflowed a traversal stack."""
+        _check(lib().crt_scene_traversal_error(self.h, _stream_ptr(stream)), "crt_scene_traversal_error")
 
     def unique_primitive_breakdown(self):
         """Scene::unique_primitive_breakdown (scene.rs:422-427): what is resident, shared prototypes once."""

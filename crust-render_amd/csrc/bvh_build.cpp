@@ -13,7 +13,10 @@
 // Compiled with -ffp-contract=off: split costs and clipped bounds are compared exactly.
 #include <cmath>
 #include <cstring>
+#include <atomic>
 #include <future>
+#include <system_error>
+#include <thread>
 #include <limits>
 #include <optional>
 
@@ -259,17 +262,44 @@ void partition_by_bin(std::vector<PrimRef> &&refs, const ObjSplit &o, std::vecto
 
 Subtree build_subtree(const std::vector<Prim> &prims, std::vector<PrimRef> &&refs, size_t depth, float root_area);
 
+// The reference forks with rayon::join on a bounded pool (bvh.rs:1156-1162). Here a fork takes one of a fixed
+// number of helper-thread tokens (hardware threads - 1) or, when none is free or the thread cannot be created,
+// builds both sides inline: at most that many OS threads are ever alive, however large the input. The tree is the
+// same either way (the build is deterministic, bvh.rs:22-24; tests/test_build_parity.py).
+std::atomic<int> g_build_helpers{0};
+
+int max_build_helpers() {
+  static const int n = [] {
+    unsigned hc = std::thread::hardware_concurrency();
+    return int(hc > 1 ? (hc > 64 ? 64 : hc) - 1 : 0);
+  }();
+  return n;
+}
+
 Subtree build_children(const std::vector<Prim> &prims, const Aabb &bbox, std::vector<PrimRef> &&l,
                        std::vector<PrimRef> &&r, size_t depth, float root_area, bool allow_parallel) {
-  if (allow_parallel && std::max(l.size(), r.size()) > kParallelThreshold) {  // bvh.rs:1156-1162
-    auto fut = std::async(std::launch::async,
-                          [&prims, depth, root_area](std::vector<PrimRef> v) {
-                            return build_subtree(prims, std::move(v), depth + 1, root_area);
-                          },
-                          std::move(l));
-    Subtree right = build_subtree(prims, std::move(r), depth + 1, root_area);
-    Subtree left = fut.get();
-    return merge(bbox, std::move(left), std::move(right));
+  if (allow_parallel && std::max(l.size(), r.size()) > kParallelThreshold) {
+    bool token = g_build_helpers.fetch_add(1) < max_build_helpers();
+    if (!token) g_build_helpers.fetch_sub(1);
+    if (token) {
+      std::future<Subtree> fut;
+      bool spawned = true;
+      try {
+        fut = std::async(std::launch::async, [&prims, &l, depth, root_area]() {
+          Subtree t = build_subtree(prims, std::move(l), depth + 1, root_area);
+          g_build_helpers.fetch_sub(1);
+          return t;
+        });
+      } catch (const std::system_error &) {  // thread limit reached: nothing was moved from, build inline
+        g_build_helpers.fetch_sub(1);
+        spawned = false;
+      }
+      if (spawned) {
+        Subtree right = build_subtree(prims, std::move(r), depth + 1, root_area);
+        Subtree left = fut.get();
+        return merge(bbox, std::move(left), std::move(right));
+      }
+    }
   }
   Subtree left = build_subtree(prims, std::move(l), depth + 1, root_area);
   Subtree right = build_subtree(prims, std::move(r), depth + 1, root_area);

@@ -2,14 +2,15 @@
 // The renderer entry points live in render.cpp.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstring>
+#include <exception>
 #include <new>
 #include <unordered_set>
 
 #include "crt_internal.h"
 
 namespace crt {
-int traversal_error_check(void *stream);
 const char *last_error_text();
 }
 
@@ -128,8 +129,20 @@ int crt_set_instance(CrtBuilder *b, uint32_t id, CrtScene *scene, const float l2
 
 CrtScene *crt_commit(CrtBuilder *b) {
   if (!b) return nullptr;
-  CrtScene *s = new (std::nothrow) CrtScene();
-  if (s) s->p = commit(std::move(b->b));
+  CrtScene *s = nullptr;
+  try {  // nothing may unwind through the C ABI: allocation or thread-creation failures become NULL + crt_last_error
+    s = new CrtScene();
+    s->p = commit(std::move(b->b));
+    if (!s->p) { delete s; s = nullptr; }  // refused (instance nesting): commit left the reason in crt_last_error
+  } catch (const std::exception &e) {
+    set_error_text("commit: %s", e.what());
+    delete s;
+    s = nullptr;
+  } catch (...) {
+    set_error_text("commit: unknown failure");
+    delete s;
+    s = nullptr;
+  }
   delete b;
   return s;
 }
@@ -152,6 +165,25 @@ int crt_scene_bounds(const CrtScene *s, float out[6]) {
 uint32_t crt_scene_geometry_count(const CrtScene *s) { return s ? s->p->n_geoms : 0; }
 int crt_scene_has_motion(const CrtScene *s) { return s ? (s->p->has_motion ? 1 : 0) : 0; }
 size_t crt_scene_primitive_count(const CrtScene *s) { return s ? s->p->bvh.prims.size() : 0; }
+int crt_scene_primitive_extents(const CrtScene *s, size_t *count, float *scene_diagonal, float *mean_diagonal,
+                                float *max_diagonal) {  // scene.rs:446-455, bvh.rs:335-345
+  if (!s) return CRT_ERR_BAD_ARG;
+  const Bvh &b = s->p->bvh;
+  auto length = [](F3 v) { return std::sqrt((v.x * v.x + v.y * v.y) + v.z * v.z); };  // Vec3A::length
+  float sum = 0.0f, mx = 0.0f;
+  for (const Prim &p : b.prims) {
+    const Aabb bb = prim_bbox(p);
+    const float d = length(bb.mx - bb.mn);
+    sum += d;
+    mx = d > mx ? d : mx;  // f32::max
+  }
+  const size_t n = b.prims.size();
+  if (count) *count = n;
+  if (scene_diagonal) *scene_diagonal = b.has_bbox ? length(b.root_bbox.mx - b.root_bbox.mn) : 0.0f;
+  if (mean_diagonal) *mean_diagonal = n == 0 ? 0.0f : sum / float(n);
+  if (max_diagonal) *max_diagonal = mx;
+  return CRT_OK;
+}
 int crt_scene_primitive_breakdown(const CrtScene *s, size_t out[5]) {
   if (!s || !out) return CRT_ERR_BAD_ARG;
   out[0] = out[1] = out[2] = out[3] = out[4] = 0;
@@ -212,29 +244,48 @@ int crt_intersect_n(CrtScene *s, const CrtRay *d_rays, size_t n, float t_min, fl
   if (!s || (n && (!d_rays || !d_hits))) return CRT_ERR_BAD_ARG;
   int rc = s->p->ensure_device();
   if (rc != CRT_OK) return rc;
-  return launch_intersect_n(s->p->dev->view, d_rays, n, t_min, t_max, d_hits, stream, nullptr);
+  return launch_intersect_n(s->p->dev->view, d_rays, n, t_min, t_max, d_hits, stream, nullptr, s->p->dev->err);
 }
 int crt_occluded_n(CrtScene *s, const CrtRay *d_rays, size_t n, float t_min, float t_max, uint32_t *d_out,
                    void *stream) {
   if (!s || (n && (!d_rays || !d_out))) return CRT_ERR_BAD_ARG;
   int rc = s->p->ensure_device();
   if (rc != CRT_OK) return rc;
-  return launch_occluded_n(s->p->dev->view, d_rays, n, t_min, t_max, d_out, stream, nullptr);
+  return launch_occluded_n(s->p->dev->view, d_rays, n, t_min, t_max, d_out, stream, nullptr, s->p->dev->err);
+}
+
+// Reads and clears a device error word after the stream has drained: CRT_OK, or CRT_ERR_STACK when a traversal of
+// the launches since the last read overflowed its stack (bit 0) or met instance nesting beyond the frames (bit 1).
+static int take_error_word(uint32_t *d_err, void *stream) {
+  uint32_t h = 0;
+  if (hipMemcpyAsync(&h, d_err, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return CRT_ERR_NO_DEVICE;
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return CRT_ERR_NO_DEVICE;
+  if (!h) return CRT_OK;
+  (void)hipMemsetAsync(d_err, 0, sizeof h, (hipStream_t)stream);
+  set_error_text("traversal error word 0x%x (1 = stack overflow, 2 = instance nesting)", h);
+  return CRT_ERR_STACK;
+}
+
+int crt_scene_traversal_error(CrtScene *s, void *stream) {
+  if (!s) return CRT_ERR_BAD_ARG;
+  if (!s->p->dev) return CRT_OK;  // never queried
+  return take_error_word(s->p->dev->err, stream);
 }
 
 static int with_stats(CrtScene *s, void *stream, CrtTravStats *host_stats,
-                      int (*launch)(const DevScene &, void *, CrtTravStats *, void *), void *ctx) {
+                      int (*launch)(const DevScene &, void *, CrtTravStats *, uint32_t *, void *), void *ctx) {
   int rc = s->p->ensure_device();
   if (rc != CRT_OK) return rc;
   CrtTravStats *d = nullptr;
   if (hipMalloc(&d, sizeof(CrtTravStats)) != hipSuccess) return CRT_ERR_NO_DEVICE;
   (void)hipMemsetAsync(d, 0, sizeof(CrtTravStats), (hipStream_t)stream);
-  rc = launch(s->p->dev->view, stream, d, ctx);
+  rc = launch(s->p->dev->view, stream, d, s->p->dev->err, ctx);
   CrtTravStats h;
   if (rc == CRT_OK && hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess)
     rc = CRT_ERR_NO_DEVICE;
   if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) rc = CRT_ERR_NO_DEVICE;
   (void)hipFree(d);
+  if (rc == CRT_OK) rc = take_error_word(s->p->dev->err, stream);  // these forms synchronise anyway: surface it
   if (rc == CRT_OK && host_stats) {
     for (int k = 0; k < 2; k++) {
       host_stats->queries[k] += h.queries[k]; host_stats->nodes[k] += h.nodes[k];
@@ -257,9 +308,9 @@ int crt_intersect_n_stats(CrtScene *s, const CrtRay *d_rays, size_t n, float t_m
   NArgs a{d_rays, n, t_min, t_max, d_hits};
   return with_stats(
       s, stream, host_stats,
-      [](const DevScene &v, void *st, CrtTravStats *d, void *c) {
+      [](const DevScene &v, void *st, CrtTravStats *d, uint32_t *e, void *c) {
         NArgs *a = static_cast<NArgs *>(c);
-        return launch_intersect_n(v, a->rays, a->n, a->t_min, a->t_max, static_cast<CrtRayHit *>(a->out), st, d);
+        return launch_intersect_n(v, a->rays, a->n, a->t_min, a->t_max, static_cast<CrtRayHit *>(a->out), st, d, e);
       },
       &a);
 }
@@ -269,48 +320,93 @@ int crt_occluded_n_stats(CrtScene *s, const CrtRay *d_rays, size_t n, float t_mi
   NArgs a{d_rays, n, t_min, t_max, d_out};
   return with_stats(
       s, stream, host_stats,
-      [](const DevScene &v, void *st, CrtTravStats *d, void *c) {
+      [](const DevScene &v, void *st, CrtTravStats *d, uint32_t *e, void *c) {
         NArgs *a = static_cast<NArgs *>(c);
-        return launch_occluded_n(v, a->rays, a->n, a->t_min, a->t_max, static_cast<uint32_t *>(a->out), st, d);
+        return launch_occluded_n(v, a->rays, a->n, a->t_min, a->t_max, static_cast<uint32_t *>(a->out), st, d, e);
       },
       &a);
 }
 
-// Single-ray forms: stage through a small device buffer and synchronise. Meant for drop-in use by a
-// per-pixel host integrator and for API-semantics tests, not for throughput.
-int crt_intersect1(CrtScene *s, const CrtRay *ray, float t_min, float t_max, CrtRayHit *hit) {
-  if (!s || !ray || !hit) return CRT_ERR_BAD_ARG;
+// Single-ray forms, for drop-in use by a per-pixel host integrator whose worker threads each call
+// Scene::intersect / occluded one ray at a time (tracer.rs:428, :478; "Queries are &self and thread-safe",
+// scene.rs:344). Every calling thread owns a persistent staging area — a pinned host record, a device record
+// (ray, result, this thread's error word) and a non-blocking stream — created on its first call, so a query is
+// one host-to-device copy, one launch and one device-to-host copy on the thread's own stream: no allocation, no
+// device-wide synchronisation, nothing shared between threads. crt_thread_release frees the calling thread's area.
+}  // extern "C"
+namespace {
+struct Staging {
+  struct Rec { CrtRay ray; CrtRayHit hit; uint32_t occ; uint32_t err; };
+  Rec *host = nullptr;   // pinned
+  Rec *dev = nullptr;
+  hipStream_t stream = nullptr;
+  int device = -1;
+  bool ok() const { return host && dev && stream; }
+  void release() {
+    if (stream) (void)hipStreamDestroy(stream);
+    if (dev) (void)hipFree(dev);
+    if (host) (void)hipHostFree(host);
+    host = nullptr; dev = nullptr; stream = nullptr; device = -1;
+  }
+  bool acquire() {
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) return false;
+    if (ok() && device == cur) return true;
+    release();
+    if (!CRT_HIP_OK(hipHostMalloc(reinterpret_cast<void **>(&host), sizeof(Rec), hipHostMallocDefault)) ||
+        !CRT_HIP_OK(hipMalloc(reinterpret_cast<void **>(&dev), sizeof(Rec))) ||
+        !CRT_HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)) ||
+        !CRT_HIP_OK(hipMemset(dev, 0, sizeof(Rec)))) {
+      release();
+      return false;
+    }
+    device = cur;
+    return true;
+  }
+};
+// Deliberately not freed by a thread_local destructor: at process exit that would run after the HIP runtime's own
+// teardown. A thread that ends early calls crt_thread_release(); otherwise the area (≈ 200 bytes of HBM, one
+// stream) lives as long as the process.
+thread_local Staging t_staging;
+
+template <bool ANY>
+int query1(CrtScene *s, const CrtRay *ray, float t_min, float t_max, CrtRayHit *hit) {
   int rc = s->p->ensure_device();
   if (rc != CRT_OK) return rc;
-  char *d = nullptr;
-  if (hipMalloc(&d, sizeof(CrtRay) + sizeof(CrtRayHit)) != hipSuccess) return CRT_ERR_NO_DEVICE;
-  CrtRay *dr = reinterpret_cast<CrtRay *>(d);
-  CrtRayHit *dh = reinterpret_cast<CrtRayHit *>(d + sizeof(CrtRay));
-  rc = hipMemcpy(dr, ray, sizeof(CrtRay), hipMemcpyHostToDevice) == hipSuccess ? CRT_OK : CRT_ERR_NO_DEVICE;
-  if (rc == CRT_OK) rc = launch_intersect_n(s->p->dev->view, dr, 1, t_min, t_max, dh, nullptr, nullptr);
-  if (rc == CRT_OK) rc = traversal_error_check(nullptr);
-  if (rc == CRT_OK && hipMemcpy(hit, dh, sizeof(CrtRayHit), hipMemcpyDeviceToHost) != hipSuccess) rc = CRT_ERR_NO_DEVICE;
-  (void)hipFree(d);
+  Staging &g = t_staging;
+  if (!g.acquire()) return CRT_ERR_NO_DEVICE;
+  g.host->ray = *ray;
+  if (!CRT_HIP_OK(hipMemcpyAsync(&g.dev->ray, &g.host->ray, sizeof(CrtRay), hipMemcpyHostToDevice, g.stream)))
+    return CRT_ERR_NO_DEVICE;
+  rc = ANY ? launch_occluded_n(s->p->dev->view, &g.dev->ray, 1, t_min, t_max, &g.dev->occ, g.stream, nullptr, &g.dev->err)
+           : launch_intersect_n(s->p->dev->view, &g.dev->ray, 1, t_min, t_max, &g.dev->hit, g.stream, nullptr, &g.dev->err);
   if (rc != CRT_OK) return rc;
+  // result + error word in one copy (hit, occ, err are contiguous)
+  if (!CRT_HIP_OK(hipMemcpyAsync(&g.host->hit, &g.dev->hit, sizeof(CrtRayHit) + 2 * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                 g.stream)) ||
+      !CRT_HIP_OK(hipStreamSynchronize(g.stream)))
+    return CRT_ERR_NO_DEVICE;
+  if (g.host->err) {  // this call's own word: another thread's or scene's overflow cannot show up here
+    (void)hipMemsetAsync(&g.dev->err, 0, sizeof(uint32_t), g.stream);
+    set_error_text("traversal error word 0x%x (1 = stack overflow, 2 = instance nesting)", g.host->err);
+    return CRT_ERR_STACK;
+  }
+  if (ANY) return g.host->occ ? 1 : 0;
+  *hit = g.host->hit;
   return hit->geom_id != CRT_INVALID_ID ? 1 : 0;
+}
+}  // namespace
+extern "C" {
+
+int crt_intersect1(CrtScene *s, const CrtRay *ray, float t_min, float t_max, CrtRayHit *hit) {
+  if (!s || !ray || !hit) return CRT_ERR_BAD_ARG;
+  return query1<false>(s, ray, t_min, t_max, hit);
 }
 int crt_occluded1(CrtScene *s, const CrtRay *ray, float t_min, float t_max) {
   if (!s || !ray) return CRT_ERR_BAD_ARG;
-  int rc = s->p->ensure_device();
-  if (rc != CRT_OK) return rc;
-  char *d = nullptr;
-  if (hipMalloc(&d, sizeof(CrtRay) + sizeof(uint32_t)) != hipSuccess) return CRT_ERR_NO_DEVICE;
-  CrtRay *dr = reinterpret_cast<CrtRay *>(d);
-  uint32_t *dout = reinterpret_cast<uint32_t *>(d + sizeof(CrtRay));
-  uint32_t h = 0;
-  rc = hipMemcpy(dr, ray, sizeof(CrtRay), hipMemcpyHostToDevice) == hipSuccess ? CRT_OK : CRT_ERR_NO_DEVICE;
-  if (rc == CRT_OK) rc = launch_occluded_n(s->p->dev->view, dr, 1, t_min, t_max, dout, nullptr, nullptr);
-  if (rc == CRT_OK) rc = traversal_error_check(nullptr);
-  if (rc == CRT_OK && hipMemcpy(&h, dout, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) rc = CRT_ERR_NO_DEVICE;
-  (void)hipFree(d);
-  if (rc != CRT_OK) return rc;
-  return h ? 1 : 0;
+  return query1<true>(s, ray, t_min, t_max, nullptr);
 }
+void crt_thread_release(void) { t_staging.release(); }
 
 size_t crt_shard_pixels(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, uint32_t *out) {
   if (world == 0 || rank >= world) return 0;

@@ -104,6 +104,10 @@ struct Bvh {
   Aabb root_bbox{};
 };
 
+// Instance nesting the traversal kernels carry frames for (kernels/traverse.hip.h kMaxLevels; the importer's own
+// limit, usd_import.rs:60 MAX_INSTANCE_NESTING): commit refuses deeper scenes instead of skipping instances at trace time.
+constexpr uint32_t kMaxInstanceLevels = 8;
+
 Aabb prim_bbox(const Prim &p);
 void build_bvh(Bvh &out, std::vector<Prim> &&prims);  // bvh.rs:300-327
 
@@ -148,6 +152,7 @@ struct DevScene {
 struct DeviceImage {
   void *blob = nullptr;
   size_t bytes[7] = {0, 0, 0, 0, 0, 0, 0};  // nodes, leaves, packets, indices, prims, instances, normals
+  uint32_t *err = nullptr;  // this scene's traversal error word (the blob's last 256 bytes): crt_scene_traversal_error
   DevScene view{};
   ~DeviceImage();
 };
@@ -156,6 +161,7 @@ struct Scene : std::enable_shared_from_this<Scene> {
   Bvh bvh;
   uint32_t n_geoms = 0;
   bool has_motion = false;
+  uint32_t depth = 1;  // levels of instancing below and including this scene: 1 = no instances
   std::mutex dev_mu;
   std::unique_ptr<DeviceImage> dev;  // built on first query
   int ensure_device();               // CRT_OK or CRT_ERR_NO_DEVICE
@@ -184,11 +190,14 @@ std::shared_ptr<Scene> commit(Builder &&b);  // scene.rs:226-341
 // ---------------------------------------------------------------------------------------------
 // Device launches (kernels/traverse.hip)
 // ---------------------------------------------------------------------------------------------
+// d_err: device word the kernels OR their error bits into (1 = traversal stack overflow, 2 = instance nesting).
 int launch_intersect_n(const DevScene &s, const CrtRay *d_rays, size_t n, float t_min, float t_max, CrtRayHit *d_hits,
-                       void *stream, CrtTravStats *d_stats);
+                       void *stream, CrtTravStats *d_stats, uint32_t *d_err);
 int launch_occluded_n(const DevScene &s, const CrtRay *d_rays, size_t n, float t_min, float t_max, uint32_t *d_out,
-                      void *stream, CrtTravStats *d_stats);
+                      void *stream, CrtTravStats *d_stats, uint32_t *d_err);
 int device_ok();
+// printf-style text for crt_last_error() on this thread (failures that are not HIP calls).
+void set_error_text(const char *fmt, ...);
 
 // Records the failing HIP call for crt_last_error() and returns false.
 bool hip_failed(int /*hipError_t*/ err, const char *what, const char *file, int line);

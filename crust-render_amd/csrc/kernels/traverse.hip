@@ -2,6 +2,8 @@
 // Compile with -ffp-contract=off (see traverse.hip.h).
 #include "traverse_pool.hip.h"
 
+static_assert(crt::dev::kMaxLevels == (int)crt::kMaxInstanceLevels, "commit's nesting limit is the kernels' frame count");
+
 namespace crt {
 
 using namespace dev;
@@ -100,16 +102,6 @@ __global__ __launch_bounds__(kBlock) void occluded_n_kernel(DevScene S, const Cr
   if (STATS) flush_stats(st, stats, done);
 }
 
-uint32_t *device_err_word() {
-  static uint32_t *p = [] {
-    uint32_t *q = nullptr;
-    if (!CRT_HIP_OK(hipMalloc(&q, sizeof(uint32_t)))) return (uint32_t *)nullptr;
-    (void)hipMemset(q, 0, sizeof(uint32_t));
-    return q;
-  }();
-  return p;
-}
-
 int grid_for(size_t n) {
   static int cus = [] {
     hipDeviceProp_t prop;
@@ -125,24 +117,10 @@ int grid_for(size_t n) {
 
 }  // namespace
 
-int traversal_error_check(void *stream) {
-  uint32_t *e = device_err_word();
-  if (!e) return CRT_ERR_NO_DEVICE;
-  uint32_t h = 0;
-  if (hipMemcpyAsync(&h, e, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return CRT_ERR_NO_DEVICE;
-  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return CRT_ERR_NO_DEVICE;
-  if (h) {
-    (void)hipMemsetAsync(e, 0, sizeof h, (hipStream_t)stream);
-    return CRT_ERR_STACK;
-  }
-  return CRT_OK;
-}
-
 int launch_intersect_n(const DevScene &s, const CrtRay *d_rays, size_t n, float t_min, float t_max, CrtRayHit *d_hits,
-                       void *stream, CrtTravStats *d_stats) {
+                       void *stream, CrtTravStats *d_stats, uint32_t *e) {
   if (n == 0) return CRT_OK;
-  uint32_t *e = device_err_word();
-  if (!e) return CRT_ERR_NO_DEVICE;
+  if (!e) return CRT_ERR_BAD_ARG;
   const int grid = grid_for(n);
   if (d_stats)
     hipLaunchKernelGGL(intersect_n_kernel<true>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, s, d_rays, n, t_min,
@@ -154,10 +132,9 @@ int launch_intersect_n(const DevScene &s, const CrtRay *d_rays, size_t n, float 
 }
 
 int launch_occluded_n(const DevScene &s, const CrtRay *d_rays, size_t n, float t_min, float t_max, uint32_t *d_out,
-                      void *stream, CrtTravStats *d_stats) {
+                      void *stream, CrtTravStats *d_stats, uint32_t *e) {
   if (n == 0) return CRT_OK;
-  uint32_t *e = device_err_word();
-  if (!e) return CRT_ERR_NO_DEVICE;
+  if (!e) return CRT_ERR_BAD_ARG;
   const int grid = grid_for(n);
   if (d_stats)
     hipLaunchKernelGGL(occluded_n_kernel<true>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, s, d_rays, n, t_min,

@@ -37,7 +37,10 @@ namespace dev {
 // per scene (DevScene::pool_stack); both fit the same arena.
 constexpr int kPoolStack = CRT_POOL_STACK;       // flat scenes
 constexpr int kPoolStackDeep = 10;               // instance-heavy scenes
-constexpr int kPoolSpill = 256 - kPoolStack;     // private part: same total capacity as the one-ray-per-lane kernel
+// Private part of the stack. sp lives in 8 bits of the ctl word, so LDS part + private part must not exceed 255 with
+// EITHER split: a push at the limit then takes the err path (CRT_ERR_STACK) instead of wrapping into `base`.
+constexpr int kPoolSpill = 255 - (CRT_POOL_STACK > 10 ? CRT_POOL_STACK : 10);
+static_assert(CRT_POOL_STACK + kPoolSpill <= 255 && 10 + kPoolSpill <= 255, "sp must fit the ctl word's 8 bits");
 constexpr int kFetchMin = CRT_FETCH_MIN;     // fetch new rays once this many lanes have a free slot
 #ifndef CRT_EMIT_BIAS
 #define CRT_EMIT_BIAS 16
@@ -66,6 +69,7 @@ constexpr int pool_lds_dwords(int stack) { return (4 + 4 + 2 + 5 + stack) * ROWS
 enum : uint32_t { PH_FREE = 0, PH_NODE = 1, PH_PACKET = 2, PH_SCALAR = 3, PH_EXIT = 4, PH_EMIT = 5 };
 
 // ctl word: sp[0:8) base[8:16) level[16:19) has_packets[19] kz[20:22) swap[22]
+// aux word: found-in-level bits [0:8) (bit 0 doubles as "hit" / "occluded"), scalar entries left in the leaf [8:32)
 __device__ __forceinline__ uint32_t ctl_pack(uint32_t sp, uint32_t base, uint32_t level, uint32_t hp, uint32_t kz,
                                              uint32_t swap, uint32_t phase) {
   return sp | (base << 8) | (level << 16) | (hp << 19) | (kz << 20) | (swap << 22) | (phase << 23);
@@ -539,7 +543,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
         uint32_t cursor = W(W_CURSOR, row);
         uint32_t aux = W(W_AUX, row);
         const uint32_t rmask = W(W_MASK, row);
-        uint32_t rem = (aux >> 8) & 0xffu;
+        uint32_t rem = aux >> 8;  // 24 bits: a leaf's scalar list is not limited to 255 entries (make_leaf fallbacks)
         float closest = g0.w;
         const float dx = rd(side_d, row, 0), dy = rd(side_d, row, 1), dz = rd(side_d, row, 2), time = rd(side_d, row, 3);
         const uint32_t pi = S.indices[cursor];

@@ -7,6 +7,7 @@
 // another root node in the same arrays.
 #include <hip/hip_runtime.h>
 
+#include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <unordered_map>
@@ -64,6 +65,7 @@ std::shared_ptr<Scene> commit(Builder &&b) {  // scene.rs:226-341
   std::vector<Prim> prims;
   prims.reserve(total);
   bool has_motion = false;
+  uint32_t depth = 1;
   for (size_t gi = 0; gi < b.geoms.size(); gi++) {
     Geom &g = b.geoms[gi];
     const uint32_t geom_id = uint32_t(gi);
@@ -122,11 +124,20 @@ std::shared_ptr<Scene> commit(Builder &&b) {  // scene.rs:226-341
           p.bounds = transformed_aabb(inner, g.l2w);
         }
         has_motion |= g.has_end || g.scene->has_motion;  // scene.rs:322
+        if (g.scene->depth + 1 > depth) depth = g.scene->depth + 1;
         prims.push_back(std::move(p));
         break;
       }
     }
   }
+  if (depth > kMaxInstanceLevels) {
+    // The reference's kernel recurses without a limit (prim.rs:345-378); its importer stops at 8 levels
+    // (usd_import.rs:60). The device kernels keep one frame per level, so a deeper scene is refused here, loudly,
+    // instead of silently skipping its innermost instances at trace time.
+    set_error_text("commit: %u levels of instance nesting, the kernels carry %u", depth, kMaxInstanceLevels);
+    return nullptr;
+  }
+  scene->depth = depth;
   scene->has_motion = has_motion;
   build_bvh(scene->bvh, std::move(prims));
   return scene;
@@ -146,6 +157,13 @@ bool hip_failed(int err, const char *what, const char *file, int line) {
   std::snprintf(g_last_error, sizeof g_last_error, "%s -> %s (%d) at %s:%d", what, hipGetErrorString((hipError_t)err), err,
                 file, line);
   return true;
+}
+
+void set_error_text(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  std::vsnprintf(g_last_error, sizeof g_last_error, fmt, ap);
+  va_end(ap);
 }
 
 int device_ok() {
@@ -313,8 +331,11 @@ int Scene::ensure_device() {
     total += (sz[i] + 255) & ~size_t(255);  // every array starts on a 256-byte boundary
     img->bytes[i] = sz[i];
   }
-  if (total == 0) total = 256;
+  const size_t err_off = total;
+  total += 256;  // the scene's traversal error word
   if (!CRT_HIP_OK(hipMalloc(&img->blob, total))) return CRT_ERR_NO_DEVICE;
+  if (!CRT_HIP_OK(hipMemset(static_cast<char *>(img->blob) + err_off, 0, 256))) return CRT_ERR_NO_DEVICE;
+  img->err = reinterpret_cast<uint32_t *>(static_cast<char *>(img->blob) + err_off);
   for (int i = 0; i < 7; i++)
     if (sz[i] && !CRT_HIP_OK(hipMemcpy(static_cast<char *>(img->blob) + off[i], src[i], sz[i], hipMemcpyHostToDevice)))
       return CRT_ERR_NO_DEVICE;

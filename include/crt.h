@@ -105,7 +105,9 @@ int crt_set_triangles(CrtBuilder *b, uint32_t id, const float *verts, size_t n_v
 int crt_set_sphere(CrtBuilder *b, uint32_t id, const float center[3], float radius);
 int crt_set_instance(CrtBuilder *b, uint32_t id, CrtScene *scene, const float l2w[12], const float *l2w_end);
 /* commit(self) -> Scene: consumes the builder (scene.rs:226). Deterministic SBVH build + BVH4 collapse
- * on the host (bvh.rs:300-327); the device image is created on first query. */
+ * on the host (bvh.rs:300-327) on a bounded number of helper threads; the device image is created on first query.
+ * Returns NULL (reason in crt_last_error) when memory or threads run out, or when instances nest deeper than the 8
+ * levels the kernels carry frames for (the reference's importer stops at the same depth, usd_import.rs:60). */
 CrtScene *crt_commit(CrtBuilder *b);
 
 /* ---- Scene (scene.rs:351-479) ---- */
@@ -120,6 +122,10 @@ int crt_scene_primitive_breakdown(const CrtScene *s, size_t out[5]);
 /* unique_primitive_breakdown: the same five counts over what is resident in memory — instanced scenes are
  * descended, each distinct prototype once however many placements share it             scene.rs:422-427 */
 int crt_scene_unique_primitive_breakdown(const CrtScene *s, size_t out[5]);
+/* primitive_extents -> (count, scene diagonal, mean primitive diagonal, max primitive diagonal): the "BVH that will
+ * not cull" diagnostic over the top-level primitives' boxes. Any out pointer may be NULL.   scene.rs:446-455 */
+int crt_scene_primitive_extents(const CrtScene *s, size_t *count, float *scene_diagonal, float *mean_diagonal,
+                                float *max_diagonal);
 /* memory_footprint: prim_nodes, boxed_prims, bvh_nodes, leaves, packets, indices (device bytes) scene.rs:459 */
 int crt_scene_memory_footprint(CrtScene *s, size_t out[6]);
 /* Host copies of the committed tree of THIS scene (local indices), for build-parity checks:
@@ -127,16 +133,26 @@ int crt_scene_memory_footprint(CrtScene *s, size_t out[6]);
 int crt_scene_tree(const CrtScene *s, size_t counts[5], const void **nodes128, const void **leaves16,
                    const void **packets192, const uint32_t **indices);
 
-/* Scene::intersect(&ray, t_min, t_max) -> Option<RayHit>: 1 = hit, 0 = miss, <0 error      scene.rs:354 */
+/* Scene::intersect(&ray, t_min, t_max) -> Option<RayHit>: 1 = hit, 0 = miss, <0 error      scene.rs:354
+ * Thread-safe as the reference's queries are ("&self and thread-safe", scene.rs:344): every calling thread stages
+ * through its own persistent pinned/device record and its own stream, created on its first call — no allocation,
+ * no device-wide synchronisation and no state shared between threads per query. */
 int crt_intersect1(CrtScene *s, const CrtRay *ray, float t_min, float t_max, CrtRayHit *hit);
 /* Scene::occluded(&ray, t_min, t_max) -> bool: 1 / 0 / <0                                  scene.rs:370 */
 int crt_occluded1(CrtScene *s, const CrtRay *ray, float t_min, float t_max);
+/* Frees the calling thread's single-ray staging area (a worker thread about to exit calls this; optional). */
+void crt_thread_release(void);
 /* Batched forms for the wavefront integrator: d_rays / d_hits / d_out are DEVICE pointers,
  * n rays, launched on `stream` without synchronising. d_out: one u32 per ray (1 = occluded). */
 int crt_intersect_n(CrtScene *s, const CrtRay *d_rays, size_t n, float t_min, float t_max, CrtRayHit *d_hits,
                     void *stream);
 int crt_occluded_n(CrtScene *s, const CrtRay *d_rays, size_t n, float t_min, float t_max, uint32_t *d_out,
                    void *stream);
+/* The batched forms do not synchronise, so they cannot report a traversal that overflowed its stack (more than 255
+ * pending entries): the kernels OR that into the SCENE's error word. This call drains `stream`, reads and clears
+ * the word: CRT_OK, or CRT_ERR_STACK if any launch on this scene since the last call met the condition (the
+ * affected rays' results are then undefined). The single-ray and *_stats forms check their own launches. */
+int crt_scene_traversal_error(CrtScene *s, void *stream);
 /* Same launches with the traversal counters compiled in; counts are added into *host_stats after a
  * stream sync. Take counts from these and timings from the plain forms (bvh.rs:31-38). */
 int crt_intersect_n_stats(CrtScene *s, const CrtRay *d_rays, size_t n, float t_min, float t_max, CrtRayHit *d_hits,

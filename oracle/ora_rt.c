@@ -1234,6 +1234,20 @@ void ora_primitive_breakdown(const OraScene *s, size_t out[5]) { /* scene.rs:409
     out[k == PRIM_TRI ? 0 : k == PRIM_SPHERE ? 1 : 4]++;
   }
 }
+/* scene.rs:446-455 + bvh.rs:335-345: (count, scene diagonal, mean and max diagonal of the top-level primitives' boxes) */
+size_t ora_primitive_extents(const OraScene *s, float out[3]) {
+  float sum = 0.0f, mx = 0.0f;
+  for (size_t i = 0; i < s->bvh.n_prims; i++) {
+    const OraAabb b = prim_bbox(&s->bvh.prims[i]);
+    const float d = v3_len(v3_sub(b.mx, b.mn));
+    sum += d;
+    mx = d > mx ? d : mx;
+  }
+  out[0] = s->bvh.has_bbox ? v3_len(v3_sub(s->bvh.root_bbox.mx, s->bvh.root_bbox.mn)) : 0.0f;
+  out[1] = s->bvh.n_prims == 0 ? 0.0f : sum / (float)s->bvh.n_prims;
+  out[2] = mx;
+  return s->bvh.n_prims;
+}
 /* bvh.rs:397-416: every primitive of this tree once; an instanced scene is entered the first time it is met. */
 typedef struct { const OraScene **seen; size_t n, cap; } Visited;
 static void accumulate_unique(const OraScene *s, Visited *vis, size_t acc[5]) {

@@ -60,6 +60,7 @@ int ora_has_motion(const OraScene *s);                                   /* scen
 size_t ora_primitive_count(const OraScene *s);                           /* scene.rs:400 */
 /* out: triangles, spheres, curve_segments, cubic_curve_spans, instances */
 void ora_primitive_breakdown(const OraScene *s, size_t out[5]);          /* scene.rs:409 */
+size_t ora_primitive_extents(const OraScene *s, float out[3]);              /* scene.rs:446-455 -> count; out = scene, mean, max diagonal */
 void ora_unique_primitive_breakdown(const OraScene *s, size_t out[5]);   /* scene.rs:422-427, bvh.rs:397-416 */
 
 /* Batched helpers for tests / cpu_baseline (rays: 8 floats o,d,time,mask-bits; hits: 8 x 4-byte

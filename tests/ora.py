@@ -190,6 +190,8 @@ def lib():
     L.ora_primitive_count.restype = C.c_size_t
     L.ora_primitive_count.argtypes = [C.c_void_p]
     L.ora_primitive_breakdown.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    L.ora_primitive_extents.restype = C.c_size_t
+    L.ora_primitive_extents.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.ora_unique_primitive_breakdown.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
     L.ora_intersect_n.argtypes = [C.c_void_p, fp, C.c_size_t, C.c_float, C.c_float, fp, up, C.POINTER(C.c_uint8)]
     L.ora_occluded_n.argtypes = [C.c_void_p, fp, C.c_size_t, C.c_float, C.c_float, C.POINTER(C.c_uint8)]
@@ -365,6 +367,11 @@ class Scene:
         out = (C.c_size_t * 5)()
         fn(self.h, out)
         return dict(zip(("triangles", "spheres", "curve_segments", "cubic_curve_spans", "instances"), map(int, out)))
+
+    def primitive_extents(self):
+        out = (C.c_float * 3)()
+        n = lib().ora_primitive_extents(self.h, out)
+        return n, out[0], out[1], out[2]
 
     def primitive_breakdown(self):
         return self._breakdown(lib().ora_primitive_breakdown)

@@ -87,3 +87,72 @@ def test_out_of_range_indices_are_skipped(crt):
     b = crt.SceneBuilder()
     b.attach_triangles([(0, 0, 0), (1, 0, 0), (0, 1, 0)], [(0, 1, 2), (0, 1, 9)])  # scene.rs:251-253
     assert b.commit().primitive_count() == 1
+
+
+@pytest.mark.parametrize("name", list(scenes.ALL))
+def test_primitive_extents_match_oracle(crt, name):
+    """Scene::primitive_extents (scene.rs:446-455): count, scene diagonal, mean and max primitive diagonal, bit for bit."""
+    make, _ = scenes.ALL[name]
+    a, b = make(ora).primitive_extents(), make(crt).primitive_extents()
+    assert a[0] == b[0]
+    assert np.array_equal(np.array(a[1:], np.float32).view(np.uint32), np.array(b[1:], np.float32).view(np.uint32))
+    if a[0]:
+        assert 0.0 < b[2] <= b[3] * 1.0001 and b[3] <= b[1] * 1.0001  # mean <= max <= scene diagonal, up to f32 rounding
+
+
+def test_primitive_extents_of_an_empty_scene(crt):
+    assert crt.SceneBuilder().commit().primitive_extents() == (0, 0.0, 0.0, 0.0)
+
+
+def test_commit_refuses_instance_nesting_beyond_the_kernel_frames(crt):
+    """The device kernels carry 8 instance frames (the importer's own limit, usd_import.rs:60): a scene 8 levels deep
+    commits, a 9th level is refused at commit with the reason in crt_last_error — never skipped at trace time."""
+    b = crt.SceneBuilder()
+    b.attach_sphere((0, 0, 0), 1.0)
+    s = b.commit()
+    for depth in range(2, 9):  # levels 2..8
+        b = crt.SceneBuilder()
+        b.attach_instance(s)
+        s = b.commit()
+        assert s.primitive_count() == 1
+    b = crt.SceneBuilder()
+    b.attach_instance(s)
+    with pytest.raises(RuntimeError, match="nesting"):
+        b.commit()
+
+
+def test_large_builds_use_a_bounded_number_of_helper_threads(crt):
+    """A build large enough to fork at many levels (the reference forks with rayon::join on a bounded pool,
+    bvh.rs:1156-1162): the tree equals the oracle's, and the process never holds more threads than cores + a few."""
+    import threading
+    import time
+    rng = np.random.default_rng(3)
+    n = 120_000
+    c = rng.uniform(-50, 50, (n, 1, 3)).astype(np.float32)
+    verts = (c + rng.uniform(-0.2, 0.2, (n, 3, 3)).astype(np.float32)).reshape(-1, 3)
+    idx = np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)
+    peak = [0]
+    stop = threading.Event()
+
+    def watch():
+        while not stop.is_set():
+            with open("/proc/self/status") as f:
+                for line in f:
+                    if line.startswith("Threads:"):
+                        peak[0] = max(peak[0], int(line.split()[1]))
+            time.sleep(0.002)
+    base = threading.active_count()
+    with open("/proc/self/status") as f:
+        before = next(int(l.split()[1]) for l in f if l.startswith("Threads:"))
+    t = threading.Thread(target=watch)
+    t.start()
+    b = crt.SceneBuilder()
+    b.attach_triangles(verts, idx)
+    s = b.commit()
+    stop.set()
+    t.join()
+    import os
+    assert peak[0] - before <= (os.cpu_count() or 1) + 2, (peak[0], before, base)
+    a = ora.SceneBuilder()
+    a.attach_triangles(verts, idx)
+    _same_tree(a.commit(), s)

@@ -169,3 +169,88 @@ def test_large_batch_properties(crt):
     r = np.linalg.norm(p - centers, axis=1)
     assert np.all(r < 1.0 + 1e-4) and np.all(r > 0.98)
     assert np.all(hits["geom_id"][hit] < 27)
+
+
+def _build_pile(api, n_spheres=300, n_inst=280):
+    """Piles of more than 255 coincident primitives: 300 spheres with one centre and radius, 280 instances of one
+    prototype with one placement. No split plane separates them: the builder falls back to median splits by input
+    order (bvh.rs:1148-1152), every leaf overlaps every other, and a ray through the pile visits all of them."""
+    b = api.SceneBuilder()
+    for k in range(n_spheres):
+        b.attach_sphere((0.0, 0.0, 0.0), 1.0 + 0.0 * k, mask=1 if k < 200 else 2)  # the first 200 invisible to mask 2
+    pile = b.commit()
+    pb = api.SceneBuilder()
+    pb.attach_sphere((0.0, 0.0, 0.0), 0.5)
+    proto = pb.commit()
+    b = api.SceneBuilder()
+    for k in range(n_inst):
+        b.attach_instance(proto, api.affine(None, (4.0, 0.0, 0.0)), mask=4 if k < 270 else 2)
+    b.attach_instance(pile, api.affine(None, (0.0, 0.0, 0.0)))
+    return b.commit(), (pile, proto)
+
+
+def test_piles_of_more_than_255_coincident_primitives(crt):
+    """Rays whose category only sees the entries beyond the 255th of a pile must still find them, and the deep,
+    fully overlapping subtrees must not overflow anything silently: hits, ids and occlusion identical to the oracle,
+    and the scene's traversal error word stays clear. (With median splits a single leaf never grows past a few
+    entries — its scalar counter has 24 bits regardless, see traverse_pool.hip.h.)"""
+    import torch
+    o_scene, _k1 = _build_pile(ora)
+    p_scene, _k2 = _build_pile(crt)
+    assert o_scene.primitive_count() == p_scene.primitive_count() == 281
+    rays = fx.ray_batch(2048, 3.0)
+    rays[:, 0] += np.float32(2.0)  # between the two piles
+    k = np.arange(rays.shape[0])
+    rays[:, 7] = np.array([0xFFFFFFFF, 1, 2, 4], dtype=np.uint32)[k % 4].view(np.float32)
+    hf, ids, front = o_scene.intersect_n(rays, 0.001, INF)
+    occ = o_scene.occluded_n(rays, 0.001, INF)
+    d_rays = crt.rays_to_device(rays)
+    hits = crt.hits_to_host(p_scene.intersect_n(d_rays, 0.001, INF))
+    got_occ = p_scene.occluded_n(d_rays, 0.001, INF).cpu().numpy()
+    torch.cuda.synchronize()
+    p_scene.traversal_error()  # no stack overflow on this scene
+    hit = ids[:, 0] != 0xFFFFFFFF
+    m2 = (k % 4 == 2) & hit
+    assert m2.sum() > 20, "rays of category 2 must reach the entries past the 255th"
+    assert set(np.unique(ids[m2, 0])) <= {271, 272, 273, 274, 275, 276, 277, 278, 279, 280}
+    assert np.array_equal(hits["geom_id"], ids[:, 0]) and np.array_equal(hits["prim_id"], ids[:, 1])
+    assert np.array_equal(hits["t"][hit].view(np.uint32), hf[hit, 0].view(np.uint32))
+    assert np.array_equal(hits["normal"][hit].view(np.uint32), hf[hit, 1:4].view(np.uint32))
+    assert np.array_equal(got_occ.astype(np.uint8), occ)
+
+
+def test_single_ray_queries_from_concurrent_threads(crt):
+    """Scene::intersect / occluded are `&self` and thread-safe (scene.rs:344), called from every worker of the host
+    integrator (tracer.rs:428): eight threads, two scenes, each thread's answers equal the oracle's."""
+    import threading
+    cases = []
+    for name in ("mixed", "sphere_grid"):
+        make, extent = scenes.ALL[name]
+        rays = _batch(name, 96, extent)
+        o_scene, p_scene = make(ora), make(crt)
+        hf, ids, front = o_scene.intersect_n(rays, 0.001, INF)
+        occ = o_scene.occluded_n(rays, 0.001, INF)
+        cases.append((p_scene, rays, hf, ids, occ))
+    errors = []
+
+    def work(tid):
+        try:
+            p_scene, rays, hf, ids, occ = cases[tid % 2]
+            for i in range(tid % 3, rays.shape[0], 3):
+                r = crt.Ray(rays[i, 0:3], rays[i, 3:6], float(rays[i, 6]), int(rays[i, 7:8].view(np.uint32)[0]))
+                h = p_scene.intersect(r, 0.001, INF)
+                if ids[i, 0] == 0xFFFFFFFF:
+                    assert h is None, (tid, i)
+                else:
+                    assert h is not None and (h.geom_id, h.prim_id) == (ids[i, 0], ids[i, 1]), (tid, i)
+                    assert np.float32(h.t).view(np.uint32) == hf[i, 0].view(np.uint32), (tid, i)
+                assert bool(p_scene.occluded(r, 0.001, INF)) == bool(occ[i]), (tid, i)
+            crt.lib().crt_thread_release()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
