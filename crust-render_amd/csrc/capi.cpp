@@ -356,7 +356,9 @@ struct Staging {
     if (!CRT_HIP_OK(hipHostMalloc(reinterpret_cast<void **>(&host), sizeof(Rec), hipHostMallocDefault)) ||
         !CRT_HIP_OK(hipMalloc(reinterpret_cast<void **>(&dev), sizeof(Rec))) ||
         !CRT_HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)) ||
-        !CRT_HIP_OK(hipMemset(dev, 0, sizeof(Rec)))) {
+        // on the thread's OWN stream: a null-stream memset is asynchronous to the host and unordered against a
+        // non-blocking stream, so it could land between the first query's ray upload and its kernel
+        !CRT_HIP_OK(hipMemsetAsync(dev, 0, sizeof(Rec), stream))) {
       release();
       return false;
     }

@@ -147,7 +147,19 @@ struct DevScene {
   uint32_t has_packets;
   uint32_t n_nodes;      // nodes are numbered breadth-first, top-level tree first (see Scene::ensure_device)
   uint32_t pool_stack;   // LDS stack entries per ray the traversal engine uses for this scene (6 flat, 10 instanced)
+  uint32_t n_packets;    // Tri4 packets, top-level tree first: the first ones are staged in LDS behind the node window
+  uint32_t direct_leaves;  // leaves without packets and with 1-3 scalar entries are encoded in the child word (below)
 };
+// Device child words of a node: inner child = node index; leaf child = kLeafTag | leaf index; empty lane =
+// CRT_INVALID_ID. With DevScene::direct_leaves a leaf that holds no Tri4 packet and one to three scalar entries
+// (spheres, instances: every leaf of an instanced city's top-level tree) is written as
+//   kLeafTag | kDirectLeafTag | count << 28 | idx_first
+// so the ray goes from the node straight to the scalar list: no 16-byte Leaf fetch and no packet step that finds
+// nothing. Chosen per scene at upload (instance-heavy or packet-free scenes), like the LDS split.
+constexpr uint32_t kDirectLeafTag = 0x40000000u;
+#ifndef CRT_DIRECT_LEAVES
+#define CRT_DIRECT_LEAVES 1  // 0: neither written by the upload nor understood by the engine (A/B builds)
+#endif
 
 struct DeviceImage {
   void *blob = nullptr;

@@ -58,6 +58,36 @@ constexpr uint32_t kPrevValid = 1u << 16, kPrevDelta = 1u << 17;
 constexpr int kMediumShift = 18;             // aux[18:32): 1-based compact id of the interior medium the ray travels in
 constexpr uint32_t kMaxMedia = (1u << 14) - 1;
 
+// Streaming accesses (path state, hit records, queues, staging film: written once, read once a whole segment pass
+// later — far beyond any cache) carry the non-temporal hint, so they do not push the BVH's nodes, instance records
+// and instance records out of L2: +0.8 % (veach_mis) to +2.6 % (PointInstancedMedCity 3840x2160) over plain accesses
+// (profiles/README.md, r02h). CRT_NT=0 builds plain accesses (A/B).
+#ifndef CRT_NT
+#define CRT_NT 1
+#endif
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t nt_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_nt(float4 *p, float4 v) {
+  if (CRT_NT) { nt_f4 x = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(x, reinterpret_cast<nt_f4 *>(p)); }
+  else *p = v;
+}
+__device__ __forceinline__ void st_nt(uint4 *p, uint4 v) {
+  if (CRT_NT) { nt_u4 x = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(x, reinterpret_cast<nt_u4 *>(p)); }
+  else *p = v;
+}
+__device__ __forceinline__ void st_nt(uint32_t *p, uint32_t v) {
+  if (CRT_NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+__device__ __forceinline__ void st_nt(float *p, float v) {
+  if (CRT_NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+__device__ __forceinline__ float4 ld_nt(const float4 *p) {
+  if (CRT_NT) { const nt_f4 x = __builtin_nontemporal_load(reinterpret_cast<const nt_f4 *>(p)); return make_float4(x.x, x.y, x.z, x.w); }
+  return *p;
+}
+
 // Path state: struct-of-arrays of 16-byte records, so each plane is read and written with one
 // 16-byte-per-lane (1 KiB per wave) instruction — the widest, most efficient global access on CDNA4.
 struct PathSoA {
@@ -98,6 +128,9 @@ struct Counters {
   unsigned long long stats[8];      // RayStats (stats.rs:128-147) in declaration order
   uint32_t seg[2][kMaxGrid * kBins];  // live paths of state buffer 0 / 1, per (workgroup, bin)
   uint32_t shadow[kMaxGrid];          // shadow requests per workgroup
+  // crt_renderer_shade_class_stats: per material class, the wave executions of the vertex step that contained a
+  // vertex of the class, and how many of their 64 lanes held one (lanes / (64 * waves) = the class's lane utilisation)
+  unsigned long long cls_waves[4], cls_lanes[4];
 };
 
 __device__ __forceinline__ uint32_t dir_bin(float dx, float dy, float dz) {
@@ -145,6 +178,11 @@ struct Params {
   const uint32_t *active;
   uint32_t n_act;
   uint32_t seg_cap;             // slots per workgroup segment
+  // Material classes (shade's partition key): one byte per geom_id, and whether more than one class occurs at all —
+  // a one-class scene (cornellbox, MedCity) keeps the single pending ring and pays nothing.
+  const uint8_t *mat_class;
+  uint32_t partition;
+  uint32_t class_stats;         // count Counters::cls_* in the vertex step (diagnostic, off by default)
 };
 
 __device__ __forceinline__ float light_weight(int s, float light_pdf, float bounce_pdf) {  // tracer.rs:85-92
@@ -243,7 +281,25 @@ __global__ void k_build_media(const CrtMaterial *materials, uint32_t n, DevMediu
 // LDS buffer passed in: the per-stage kernels hand it their own array, the fused kernel (k_path) one shared arena.
 constexpr int kArenaDwords = kEngineLdsDwords > kSobolLdsWords ? kEngineLdsDwords : kSobolLdsWords;
 static_assert(sizeof(CrtMaterial) % 4 == 0, "material records are copied as dwords");
-constexpr int kMatLdsMax = (kArenaDwords - kSobolLdsWords) / (int)(sizeof(CrtMaterial) / 4);  // materials that fit beside the Sobol tables
+// Shade's pending rings (one per material class) sit at the END of the arena, the material table between the Sobol
+// tables and the rings.
+constexpr int kClasses = 4;
+constexpr uint32_t kRing = 2 * kBlock;                 // entries per class ring: < kBlock pending + one classify batch
+constexpr int kRingDwords = kClasses * (int)kRing;
+constexpr int kClassLdsMax = 1024;                     // geom ids whose class byte is staged in LDS (1 KB)
+constexpr int kMatLdsMax = (kArenaDwords - kSobolLdsWords - kRingDwords - kClassLdsMax / 4) / (int)(sizeof(CrtMaterial) / 4);
+
+// Material class = which arms of the vertex code a hit on this material runs (openpbr.rs:1026-1136 dispatches one of
+// five lobes + thin film + dispersion per lane; rt_world.rs:219-231 binds the material per geom_id). Waves whose
+// 64 vertices share a class skip the other classes' lobes with a scalar branch instead of idling through them.
+//   0 emissive (Emissive: emission only, never scatters)      1 base: diffuse + specular (dielectric or metal)
+//   2 layered: coat and / or fuzz and / or thin film on top    3 transmissive or subsurface (refraction, interior medium)
+inline uint8_t material_class(const CrtMaterial &m) {
+  if (m.kind == CRT_MAT_EMISSIVE) return 0;
+  if (m.transmission_weight > 0.0f || m.subsurface_weight > 0.0f) return 3;
+  if (m.coat_weight > 0.0f || m.fuzz_weight > 0.0f || m.thin_film_weight > 0.0f) return 2;
+  return 1;
+}
 
 __device__ __forceinline__ void generate_segment(const Params &P, const PathSoA &S, Counters *C, uint32_t sample_begin,
                                                  uint32_t n_samples, uint32_t *sobol_tab /* kSobolLdsWords */) {
@@ -280,11 +336,11 @@ __device__ __forceinline__ void generate_segment(const Params &P, const PathSoA 
     }
     V3 o, d;
     camera_get_ray(P.camera, u, v, cam[2], cam[3], o, d);
-    S.a[i] = make_float4(o.x, o.y, o.z, d.x);
-    S.b[i] = make_float4(d.y, d.z, 1.0f, 1.0f);
-    S.c[i] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
-    S.d[i] = make_uint4(new_domain(root, K_PATH).pattern /* tracer.rs:1101 */, pix, (P.max_depth & 0xffffu) << 16, sl);
-    if (P.has_motion) S.time[i] = time;
+    st_nt(&S.a[i], make_float4(o.x, o.y, o.z, d.x));
+    st_nt(&S.b[i], make_float4(d.y, d.z, 1.0f, 1.0f));
+    st_nt(&S.c[i], make_float4(1.0f, 0.0f, 0.0f, 0.0f));
+    st_nt(&S.d[i], make_uint4(new_domain(root, K_PATH).pattern /* tracer.rs:1101 */, pix, (P.max_depth & 0xffffu) << 16, sl));
+    if (P.has_motion) st_nt(&S.time[i], time);
   }
   // live slots of this segment = 1 + the largest valid k over the workgroup (valid k form a prefix)
   __shared__ uint32_t seg_max;
@@ -325,7 +381,7 @@ __device__ __forceinline__ void extend_segment(const Params &P, const PathSoA &S
     uint32_t k;
     if (!lds_take(want, &next, n, k)) return false;
     const uint32_t i = bin_slot(k, pre, P.seg_cap);
-    const float4 A = S.a[i], B = S.b[i];
+    const float4 A = ld_nt(&S.a[i]), B = ld_nt(&S.b[i]);
     in.ox = A.x; in.oy = A.y; in.oz = A.z; in.dx = A.w; in.dy = B.x; in.dz = B.y;
     in.time = P.has_motion ? S.time[i] : 0.0f;
     in.mask = mask; in.t_min = 0.001f; in.t_max = CRT_INF; in.slot = i;
@@ -334,10 +390,10 @@ __device__ __forceinline__ void extend_segment(const Params &P, const PathSoA &S
   auto emit = [&](uint32_t i, bool hit, const Hit &h, float dx, float dy, float dz) {
     if (hit) {
       const bool front = dot3(dx, dy, dz, h.nx, h.ny, h.nz) < 0.0f;  // scene.rs:356-359
-      H.h[i] = make_float4(h.t, front ? h.nx : -h.nx, front ? h.ny : -h.ny, front ? h.nz : -h.nz);
-      H.geom[i] = h.geom | (front ? 0x80000000u : 0u);
+      st_nt(&H.h[i], make_float4(h.t, front ? h.nx : -h.nx, front ? h.ny : -h.ny, front ? h.nz : -h.nz));
+      st_nt(&H.geom[i], h.geom | (front ? 0x80000000u : 0u));
     } else {
-      H.geom[i] = kInvalid;
+      st_nt(&H.geom[i], kInvalid);
     }
     done++;
   };
@@ -391,20 +447,42 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
   // rays on an open scene — so the segment is swept in two interleaved steps: CLASSIFY takes the next 256 paths,
   // finishes the escaped ones on the spot and appends the others to a ring of pending indices in LDS; SHADE takes
   // 256 pending paths at a time (fewer only when the input is exhausted), so the vertex code runs on full waves.
-  constexpr uint32_t kRing = 2 * kBlock;
-  __shared__ uint32_t ring[kRing];
-  __shared__ uint32_t ring_tail;  // entries ever appended (head is tracked in registers: uniform)
-  if (threadIdx.x == 0) ring_tail = 0;
+  // PARTITION (scenes with more than one material class): the pending vertices are kept in one ring PER CLASS and a
+  // SHADE step takes its 256 from ONE ring — the fullest — so all four waves of the step run one class's arms. The
+  // class comes from a byte table by geom_id (LDS when it fits). Per-path arithmetic does not depend on which lanes
+  // share a wave, and every output slot is private to its path, so images and counters do not change.
+  uint32_t *ring = sobol_tab + kArenaDwords - kRingDwords;        // [kClasses][kRing]
+  uint8_t *cls_lds = reinterpret_cast<uint8_t *>(ring) - kClassLdsMax;
+  __shared__ uint32_t ring_tail[kClasses];  // entries ever appended, per class (heads are tracked in registers: uniform)
+  const bool part = P.partition != 0;
+  const bool cls_in_lds = part && P.n_materials <= (uint32_t)kClassLdsMax;
+  if (threadIdx.x < kClasses) ring_tail[threadIdx.x] = 0;
+  if (cls_in_lds)
+    for (uint32_t g = threadIdx.x; g < P.n_materials; g += kBlock) cls_lds[g] = P.mat_class[g];
   __syncthreads();
-  uint32_t next_in = 0, head = 0;
+  uint32_t next_in = 0;
+  uint32_t head[kClasses], tail[kClasses];
+#pragma unroll
+  for (int c = 0; c < kClasses; c++) head[c] = 0;
   for (;;) {
-    uint32_t tail = ring_tail;  // uniform: read between two barriers, nobody appends meanwhile
+#pragma unroll
+    for (int c = 0; c < kClasses; c++) tail[c] = ring_tail[c];  // uniform: read between two barriers, nobody appends meanwhile
     __syncthreads();
-    // ---- CLASSIFY while fewer than a workgroup's worth of vertices is pending and input remains ----
-    while (tail - head < (uint32_t)kBlock && next_in < n) {
+    auto most_pending = [&](int &c_best) {
+      uint32_t best = tail[0] - head[0];
+      c_best = 0;
+#pragma unroll
+      for (int c = 1; c < kClasses; c++)
+        if (tail[c] - head[c] > best) { best = tail[c] - head[c]; c_best = c; }
+      return best;
+    };
+    int c_sel;
+    // ---- CLASSIFY while no class has a workgroup's worth of vertices pending and input remains ----
+    while (most_pending(c_sel) < (uint32_t)kBlock && next_in < n) {
       const uint32_t k_c = next_in + threadIdx.x;
       next_in += kBlock;
       bool pending = false;
+      uint32_t cls = 0;
       if (k_c < n) {
         const uint32_t i_c = bin_slot(k_c, pre, P.seg_cap);
         const uint4 D = S.d[i_c];
@@ -425,23 +503,42 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
           const V3 unit_direction = normalize(rd);
           const V3 background = splat(0.0f) + sky_gradient(unit_direction);
           L = L + beta * background;
-          staging[(D.w & 0xffffu) * P.n_act + D.y] = make_float4(L.x, L.y, L.z, 0.0f);
+          st_nt(&staging[(D.w & 0xffffu) * P.n_act + D.y], make_float4(L.x, L.y, L.z, 0.0f));
         } else {
           pending = true;
+          if (part && hg != kInvalid) {
+            const uint32_t g = hg & 0x7fffffffu;
+            cls = cls_in_lds ? cls_lds[g] : P.mat_class[g];
+          }
         }
       }
-      const uint32_t at = seg_append(pending, &ring_tail);
-      if (pending) ring[at % kRing] = k_c;
+      if (part) {
+#pragma unroll
+        for (int c = 0; c < kClasses; c++) {
+          const bool mine = pending && cls == (uint32_t)c;
+          const uint32_t at = seg_append(mine, &ring_tail[c]);
+          if (mine) ring[c * kRing + at % kRing] = k_c;
+        }
+      } else {
+        const uint32_t at = seg_append(pending, &ring_tail[0]);
+        if (pending) ring[at % kRing] = k_c;
+      }
       __syncthreads();
-      tail = ring_tail;
+#pragma unroll
+      for (int c = 0; c < kClasses; c++) tail[c] = ring_tail[c];
       __syncthreads();
     }
-    if (tail == head) break;  // uniform: input exhausted and nothing pending
-    // ---- SHADE up to a workgroup's worth of pending vertices ----
-    const uint32_t take = tail - head < (uint32_t)kBlock ? tail - head : (uint32_t)kBlock;
+    const uint32_t avail = most_pending(c_sel);
+    if (avail == 0) break;  // uniform: input exhausted and nothing pending
+    // ---- SHADE up to a workgroup's worth of pending vertices of the fullest class ----
+    const uint32_t take = avail < (uint32_t)kBlock ? avail : (uint32_t)kBlock;
     const bool active = threadIdx.x < take;
-    const uint32_t k_in = active ? ring[(head + threadIdx.x) % kRing] : 0;
-    head += take;
+    uint32_t head_sel = head[0];
+#pragma unroll
+    for (int c = 1; c < kClasses; c++) head_sel = c_sel == c ? head[c] : head_sel;
+    const uint32_t k_in = active ? ring[c_sel * kRing + (head_sel + threadIdx.x) % kRing] : 0;
+#pragma unroll
+    for (int c = 0; c < kClasses; c++) head[c] += c_sel == c ? take : 0u;
     const uint32_t i = active ? bin_slot(k_in, pre, P.seg_cap) : 0;
     bool alive = false, want_shadow = false;
     V3 L = splat(0.0f), beta = splat(1.0f);
@@ -468,6 +565,19 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
       const uint32_t hg = H.geom[i];
       const bool has_hit = hg != kInvalid;
       const uint32_t geom = hg & 0x7fffffffu;
+#ifndef CRT_NO_CLASS_STATS
+      if (P.class_stats) {  // uniform; diagnostic only
+        const uint32_t my = has_hit ? (uint32_t)P.mat_class[geom] : 0u;
+#pragma unroll
+        for (int c = 0; c < kClasses; c++) {
+          const unsigned long long m = __ballot(my == (uint32_t)c);
+          if (m && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) {
+            atomicAdd(&C->cls_waves[c], 1ull);
+            atomicAdd(&C->cls_lanes[c], (unsigned long long)__popcll(m));
+          }
+        }
+      }
+#endif
       HitRec rec;
       rec.front_face = ((hg >> 31) & 1u) != 0;
       rec.t = 0.0f; rec.normal = splat(0.0f); rec.p = splat(0.0f);
@@ -637,21 +747,21 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
     const uint32_t sl = aux & 0xffffu;
     const uint32_t film_idx = sl * P.n_act + pix;
     if (alive) {
-      N.a[j] = make_float4(n_o.x, n_o.y, n_o.z, n_d.x);
-      N.b[j] = make_float4(n_d.y, n_d.z, beta.x, beta.y);
-      N.c[j] = make_float4(beta.z, L.x, L.y, L.z);
-      N.d[j] = make_uint4(pattern, pix, ((meta & 0xffffu) + 1u) | (((meta >> 16) - 1u) << 16),
-                          sl | (n_prev_valid ? kPrevValid : 0u) | (n_delta ? kPrevDelta : 0u) | (n_med << kMediumShift));
-      if (P.n_lights) N.e[j] = make_float4(hit_p.x, hit_p.y, hit_p.z, n_ppdf);
-      if (P.has_motion) N.time[j] = time;
+      st_nt(&N.a[j], make_float4(n_o.x, n_o.y, n_o.z, n_d.x));
+      st_nt(&N.b[j], make_float4(n_d.y, n_d.z, beta.x, beta.y));
+      st_nt(&N.c[j], make_float4(beta.z, L.x, L.y, L.z));
+      st_nt(&N.d[j], make_uint4(pattern, pix, ((meta & 0xffffu) + 1u) | (((meta >> 16) - 1u) << 16),
+                                sl | (n_prev_valid ? kPrevValid : 0u) | (n_delta ? kPrevDelta : 0u) | (n_med << kMediumShift)));
+      if (P.n_lights) st_nt(&N.e[j], make_float4(hit_p.x, hit_p.y, hit_p.z, n_ppdf));
+      if (P.has_motion) st_nt(&N.time[j], time);
     } else if (active) {
-      staging[film_idx] = make_float4(L.x, L.y, L.z, 0.0f);
+      st_nt(&staging[film_idx], make_float4(L.x, L.y, L.z, 0.0f));
     }
     const uint32_t q = seg0 + seg_append(want_shadow, &lds_ctr[1]);
     if (want_shadow) {
-      Q.a[q] = make_float4(hit_p.x, hit_p.y, hit_p.z, sh_tmax);
-      Q.b[q] = make_float4(sh_d.x, sh_d.y, sh_d.z, time);
-      Q.c[q] = make_float4(sh_c.x, sh_c.y, sh_c.z, __uint_as_float(alive ? j : (kFilmTarget | film_idx)));
+      st_nt(&Q.a[q], make_float4(hit_p.x, hit_p.y, hit_p.z, sh_tmax));
+      st_nt(&Q.b[q], make_float4(sh_d.x, sh_d.y, sh_d.z, time));
+      st_nt(&Q.c[q], make_float4(sh_c.x, sh_c.y, sh_c.z, __uint_as_float(alive ? j : (kFilmTarget | film_idx))));
     }
     __syncthreads();  // every lane has read its ring entry before CLASSIFY appends again
   }
@@ -855,6 +965,7 @@ struct Renderer {
   float4 *staging = nullptr;
   float4 *film = nullptr;
   CrtMaterial *d_materials = nullptr;
+  uint8_t *d_mat_class = nullptr;  // material_class() per geom_id
   DevMedium *d_media = nullptr;  // [n_materials] by geom_id, then [n_materials] by compact id
   bool has_media = false;
   // adaptive stopping (variance_threshold > 0): per-pixel luminance statistics, sample counts and the active list
@@ -879,6 +990,7 @@ struct Renderer {
     if (C) (void)hipFree(C);
     if (film) (void)hipFree(film);
     if (d_materials) (void)hipFree(d_materials);
+    if (d_mat_class) (void)hipFree(d_mat_class);
     if (d_media) (void)hipFree(d_media);
     if (d_pstats) (void)hipFree(d_pstats);
     if (d_state) (void)hipFree(d_state);
@@ -1104,6 +1216,17 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
     ok = CRT_HIP_OK(hipMalloc(&r.d_materials, n_materials * sizeof(CrtMaterial))) &&
          CRT_HIP_OK(hipMemcpy(r.d_materials, materials, n_materials * sizeof(CrtMaterial), hipMemcpyHostToDevice));
   }
+  if (ok && n_materials) {  // shade's partition key: one class byte per geom_id
+    std::vector<uint8_t> cls(n_materials);
+    bool seen[kClasses] = {false, false, false, false};
+    for (size_t k = 0; k < n_materials; k++) { cls[k] = material_class(materials[k]); seen[cls[k]] = true; }
+    int distinct = 0;
+    for (int c = 0; c < kClasses; c++) distinct += seen[c] ? 1 : 0;
+    P.partition = distinct > 1 ? 1u : 0u;
+    if (const char *e = getenv("CRT_PARTITION")) P.partition = atoi(e) != 0 ? 1u : 0u;  // A/B runs
+    ok = CRT_HIP_OK(hipMalloc(&r.d_mat_class, n_materials)) &&
+         CRT_HIP_OK(hipMemcpy(r.d_mat_class, cls.data(), n_materials, hipMemcpyHostToDevice));
+  }
   if (ok && n_lights) {
     ok = CRT_HIP_OK(hipMalloc(&r.d_lights, n_lights * sizeof(CrtLight))) &&
          CRT_HIP_OK(hipMemcpy(r.d_lights, lights, n_lights * sizeof(CrtLight), hipMemcpyHostToDevice));
@@ -1122,6 +1245,7 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
   }
   if (!ok) { delete R; return nullptr; }
   P.materials = r.d_materials; P.lights = r.d_lights; P.pixel_index = r.d_pixels;
+  P.mat_class = r.d_mat_class;
   P.media = r.d_media; P.media_by_id = r.d_media ? r.d_media + n_materials : nullptr;
   hipDeviceProp_t prop;
   int dev = 0;
@@ -1216,6 +1340,19 @@ int crt_renderer_sample_counts(CrtRenderer *r, uint32_t *host_out) {
   if (!CRT_HIP_OK(hipStreamSynchronize(r->r.last_stream))) return CRT_ERR_NO_DEVICE;
   if (!CRT_HIP_OK(hipMemcpy(host_out, r->r.d_state, (size_t)r->r.P.n_pix * 4, hipMemcpyDeviceToHost))) return CRT_ERR_NO_DEVICE;
   for (size_t k = 0; k < r->r.P.n_pix; k++) host_out[k] &= 0x7fffffffu;
+  return CRT_OK;
+}
+int crt_renderer_shade_class_stats(CrtRenderer *r, int enable, uint64_t out_waves[4], uint64_t out_lanes[4]) {
+  if (!r) return CRT_ERR_BAD_ARG;
+  Renderer &R = r->r;
+  if (out_waves && out_lanes) {
+    unsigned long long h[8];
+    if (!CRT_HIP_OK(hipStreamSynchronize(R.last_stream))) return CRT_ERR_NO_DEVICE;
+    if (!CRT_HIP_OK(hipMemcpy(h, R.C->cls_waves, sizeof h, hipMemcpyDeviceToHost))) return CRT_ERR_NO_DEVICE;
+    if (!CRT_HIP_OK(hipMemset(R.C->cls_waves, 0, sizeof h))) return CRT_ERR_NO_DEVICE;
+    for (int c = 0; c < 4; c++) { out_waves[c] = h[c]; out_lanes[c] = h[4 + c]; }
+  }
+  if (enable >= 0) R.P.class_stats = enable ? 1u : 0u;
   return CRT_OK;
 }
 int crt_renderer_profile(CrtRenderer *r, int enable) {

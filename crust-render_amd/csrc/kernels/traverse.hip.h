@@ -208,15 +208,46 @@ __device__ __forceinline__ void motion_w2l(const DevInstance &in, float time, fl
   w2l[9] = -rx; w2l[10] = -ry; w2l[11] = -rz;
 }
 
-// Cooperative copy of the top-of-tree window into LDS; returns the number of nodes staged. Ends with a barrier.
-__device__ __forceinline__ uint32_t stage_nodes(const DevScene &S, uint32_t *lds_nodes, int cap) {
+// InstancePrim::hit's normal step (prim.rs:327, :358-364): n <- normalize(w2l.matrix3^T * n), w2l the cached one or
+// the shutter-time one (prim.rs:285-331).
+__device__ __forceinline__ void instance_normal(const DevInstance &in, float time, float &nx, float &ny, float &nz) {
+  float nm[9];
+  if ((in.flags & 2u) && time > 0.0f) {
+    float w2l[12];
+    motion_w2l(in, time, w2l);
+    nm[0] = w2l[0]; nm[1] = w2l[3]; nm[2] = w2l[6];
+    nm[3] = w2l[1]; nm[4] = w2l[4]; nm[5] = w2l[7];
+    nm[6] = w2l[2]; nm[7] = w2l[5]; nm[8] = w2l[8];
+  } else {
+    nm[0] = in.w2l[0]; nm[1] = in.w2l[3]; nm[2] = in.w2l[6];  // cached normal matrix = w2l.matrix3 transposed
+    nm[3] = in.w2l[1]; nm[4] = in.w2l[4]; nm[5] = in.w2l[7];
+    nm[6] = in.w2l[2]; nm[7] = in.w2l[5]; nm[8] = in.w2l[8];
+  }
+  float x = nm[0] * nx, y = nm[1] * nx, z = nm[2] * nx;
+  x = x + nm[3] * ny; y = y + nm[4] * ny; z = z + nm[5] * ny;
+  x = x + nm[6] * nz; y = y + nm[7] * nz; z = z + nm[8] * nz;
+  const float len = sqrtf(dot3(x, y, z, x, y, z));
+  nx = x / len; ny = y / len; nz = z / len;
+}
+
+// Cooperative copy of the scene window into LDS: the top of the tree (the first nodes, breadth-first) and, in what
+// the nodes leave free of the window's `cap` node slots, the first Tri4 packets whole (192 B each: Woop vertices,
+// primitive ids, masks) — on a small scene (veach_mis: 12 triangles) that is every node and every packet, so a ray
+// never leaves LDS until it reports its hit. Returns the nodes staged, n_pk the packets. Ends with a barrier.
+constexpr int kLdsPacketDwords = 48;
+__device__ __forceinline__ uint32_t stage_nodes(const DevScene &S, uint32_t *lds_nodes, int cap, uint32_t &n_pk) {
   const uint32_t n = S.n_nodes < (uint32_t)cap ? S.n_nodes : (uint32_t)cap;
+  const uint32_t room = ((uint32_t)cap - n) * (uint32_t)kLdsNodeStride / (uint32_t)kLdsPacketDwords;
+  n_pk = S.n_packets < room ? S.n_packets : room;
   for (uint32_t w = threadIdx.x; w < n * 8u; w += blockDim.x) {  // 7 of the 8 x 16 bytes of a node
     const uint32_t node = w >> 3, part = w & 7u;
     if (part == 7u) continue;
     const float4 v = reinterpret_cast<const float4 *>(S.nodes + node)[part];
     *reinterpret_cast<float4 *>(lds_nodes + (size_t)node * kLdsNodeStride + part * 4) = v;
   }
+  float4 *pk_dst = reinterpret_cast<float4 *>(lds_nodes + (size_t)n * kLdsNodeStride);
+  const float4 *pk_src = reinterpret_cast<const float4 *>(S.packets);
+  for (uint32_t w = threadIdx.x; w < n_pk * 12u; w += blockDim.x) pk_dst[w] = pk_src[w];
   __syncthreads();
   return n;
 }

@@ -24,6 +24,12 @@ namespace dev {
 #ifndef CRT_POOL_STACK
 #define CRT_POOL_STACK 6
 #endif
+#ifndef CRT_ROOT_REJECT
+#define CRT_ROOT_REJECT 1  // an instanced tree's root node is tested at entry; rays that touch no child never enter
+#endif
+#ifndef CRT_DEFER_NORMAL
+#define CRT_DEFER_NORMAL 1  // a level-1 instanced hit's normal is taken to world space at emit, not at every exit
+#endif
 #ifndef CRT_FETCH_MIN
 #define CRT_FETCH_MIN 40
 #endif
@@ -94,9 +100,10 @@ __device__ __forceinline__ int wave_count(bool p) {
   return n;
 }
 
-template <bool ANY, bool STATS, int ROWS, class Fetch, class Emit>
+template <bool ANY, bool STATS, int ROWS, bool DIRECT, class Fetch, class Emit>
 __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's pool_lds_dwords<ROWS>() */, float t_min,
-                              const uint32_t *lds_nodes /* staged top of the tree */, uint32_t n_lds, uint32_t pstack,
+                              const uint32_t *lds_nodes /* staged top of the tree */, uint32_t n_lds,
+                              uint32_t n_lds_pk /* packets staged behind the n_lds nodes */, uint32_t pstack,
                               uint32_t &err, LaneStats &st, Fetch fetch, Emit emit) {
   const int lane = threadIdx.x & 63;
   constexpr int RL = ROWS * 64;
@@ -105,7 +112,10 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
   float2 *f2 = reinterpret_cast<float2 *>(lds + 8 * RL);
   uint32_t *w = lds + 10 * RL;  // dword planes
   enum { W_CTL = 0, W_CUR, W_AUX, W_CURSOR, W_MASK };
-  enum { B_SLOT = 0, B_BU, B_BV, B_BDEFER, B_BGEOM };
+  // B_BINST: the level-1 instance the closest hit so far was found in, when its normal is still in that instance's
+  // space (CRT_DEFER_NORMAL) — the transform to world space (prim.rs:358-364) is then applied once, at emit,
+  // instead of at every instance exit that improved the hit; kInvalid otherwise.
+  enum { B_SLOT = 0, B_BU, B_BV, B_BDEFER, B_BGEOM, B_BINST };
   uint32_t *stk = lds + 15 * RL;
   auto at = [&](int row) { return row * 64 + lane; };
   auto W = [&](int plane, int row) -> uint32_t & { return w[plane * RL + row * 64 + lane]; };
@@ -114,7 +124,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
   // rarely touched per-ray state, private memory indexed by row
   float side_d[ROWS][4];   // direction in the current frame, shutter time
   float side_n[ROWS][4];   // pending outward normal of a sphere / instanced hit, prim id (bits)
-  uint32_t best[ROWS][5];  // caller's slot tag; u, v (bits), pending triangle, geometry id of the closest hit so far
+  uint32_t best[ROWS][6];  // caller's slot tag; u, v (bits), pending triangle, geometry id of the closest hit so far, B_BINST
   Frame frames[ROWS][kMaxLevels];
   uint32_t spill[ROWS][kPoolSpill];
 
@@ -142,18 +152,29 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
     return sp < pstack ? STK((int)sp, row) : spill[row][sp - pstack];
   };
   // What the ray does next: the rest of the leaf's scalar list, else the next stack entry, else leave the tree.
-  auto advance = [&](int row, uint32_t &sp, uint32_t base, uint32_t level, uint32_t rem, uint32_t &cur,
+  // A leaf word (kLeafTag set, not the empty marker): the leaf to run packets of, or — direct form, scenes with
+  // DevScene::direct_leaves — the scalar list itself (crt_internal.h). Counts what the packet step counts on entry.
+  constexpr bool direct_leaves = DIRECT;  // the caller instantiates the engine per DevScene::direct_leaves
+  auto leaf_word = [&](uint32_t e, uint32_t level, uint32_t &cur, uint32_t &cursor, uint32_t &rem) -> uint32_t {
+    if (direct_leaves && (e & kDirectLeafTag)) {
+      cursor = e & 0x0fffffffu;
+      rem = (e >> 28) & 3u;
+      if (STATS) { st.leaves[level > 0 ? 1 : 0]++; st.prims[level > 0 ? 1 : 0] += rem; }
+      return PH_SCALAR;
+    }
+    cur = e & ~kLeafTag;
+    cursor = 0;  // packet counter while in PH_PACKET
+    return PH_PACKET;
+  };
+  auto advance = [&](int row, uint32_t &sp, uint32_t base, uint32_t level, uint32_t &rem, uint32_t &cur,
                      uint32_t &cursor) -> uint32_t {
     if (rem > 0) return PH_SCALAR;
     for (;;) {
       if (sp == base) return level > 0 ? PH_EXIT : PH_EMIT;
       const uint32_t e = pop(row, sp);
       if (e & kLeafTag) {
-        const uint32_t li = e & ~kLeafTag;
-        if (li == (kInvalid & ~kLeafTag)) continue;
-        cur = li;
-        cursor = 0;  // packet counter while in PH_PACKET
-        return PH_PACKET;
+        if (e == kInvalid) continue;
+        return leaf_word(e, level, cur, cursor, rem);
       }
       cur = e;
       return PH_NODE;
@@ -217,6 +238,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
         W(W_CUR, row) = S.root;
         W(W_AUX, row) = 0; W(W_CURSOR, row) = 0; W(W_MASK, row) = in.mask; wr(best, row, B_SLOT, in.slot);
         wr(best, row, B_BU, 0); wr(best, row, B_BV, 0); wr(best, row, B_BDEFER, kInvalid); wr(best, row, B_BGEOM, kInvalid);
+        wr(best, row, B_BINST, kInvalid);
         wr(side_d, row, 0, in.dx); wr(side_d, row, 1, in.dy); wr(side_d, row, 2, in.dz); wr(side_d, row, 3, in.time);
 #pragma unroll
         for (int k = 0; k < ROWS; k++)
@@ -266,7 +288,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
       // carry the values along, `act` keeps them out of every effect. No zero-initialisation, no masked loads.
       const float4 g0 = f0[at(row)], g1 = f1[at(row)];
       const uint32_t c = W(W_CTL, row);
-      uint32_t cur = W(W_CUR, row), cursor = 0;
+      uint32_t cur = W(W_CUR, row), cursor = 0, rem = 0;
       uint32_t sp = c & 0xffu;
       const uint32_t base = (c >> 8) & 0xffu, level = (c >> 16) & 7u;
       bool act = mine;
@@ -342,7 +364,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
             n_tot = on[0] + on[1] + on[2] + on[3];
           }
           if (n_tot == 0) {
-            next = advance(row, sp, base, level, 0, cur, cursor);
+            next = advance(row, sp, base, level, rem, cur, cursor);
           } else {
             uint32_t top_e = 0;
             if (sp + n_tot - 1 <= pstack) {  // the stored entries fit the LDS part of the stack
@@ -365,9 +387,8 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
               }
             }
             if (top_e & kLeafTag) {
-              const uint32_t li = top_e & ~kLeafTag;
-              if (li == (kInvalid & ~kLeafTag)) next = advance(row, sp, base, level, 0, cur, cursor);
-              else { cur = li; cursor = 0; next = PH_PACKET; }
+              if (top_e == kInvalid) next = advance(row, sp, base, level, rem, cur, cursor);
+              else next = leaf_word(top_e, level, cur, cursor, rem);
             } else {
               cur = top_e;
               next = PH_NODE;
@@ -381,6 +402,10 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
         W(W_CTL, row) = (c & ~0xffu) | sp;
         W(W_CUR, row) = cur;
         if (next == PH_PACKET) W(W_CURSOR, row) = 0;
+        if (next == PH_SCALAR) {  // a direct leaf: the scalar list starts at once
+          W(W_CURSOR, row) = cursor;
+          W(W_AUX, row) = (W(W_AUX, row) & 0xffu) | (rem << 8);
+        }
       }
     } else if (q == PH_PACKET) {
       // ============ Tri4 packets of the current leaf (bvh.rs:514-562, triangle.rs:276-348), one per turn ============
@@ -404,8 +429,15 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
           const int sl = level > 0 ? 1 : 0;
           if (STATS && k == 0) { st.leaves[sl]++; st.packets[sl] += lf.pkt_count; st.prims[sl] += lf.idx_count; }
           if (k < lf.pkt_count) {
-            const Tri4 *pk = &S.packets[lf.pkt_first + k];
-            const uint4 meta = *reinterpret_cast<const uint4 *>(&pk->active);  // active, mask_and, mask_or, masks[0]
+            const uint32_t pki = lf.pkt_first + k;
+            // A packet of the staged window is read from LDS (ds_read_b128), the rest from L2. The address-space
+            // cast is kept out of the optimiser's sight only as far as needed: one select of the base pointer.
+            const Tri4 *pk = &S.packets[pki];
+            const bool pk_lds = pki < n_lds_pk;
+            const Tri4 *pk_l = reinterpret_cast<const Tri4 *>(lds_nodes + (size_t)n_lds * kLdsNodeStride) + (pk_lds ? pki : 0u);
+            uint4 meta;  // active, mask_and, mask_or, masks[0]
+            if (pk_lds) { meta = *reinterpret_cast<const uint4 *>(&pk_l->active); asm volatile("" : "+v"(meta.x)); }
+            else meta = *reinterpret_cast<const uint4 *>(&pk->active);
             uint32_t m;                                                         // triangle.rs:257-271
             if (rmask & meta.y) m = meta.x;
             else if ((rmask & meta.z) == 0) m = 0;
@@ -413,7 +445,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
               m = 0;
 #pragma unroll
               for (int l = 0; l < 4; l++)
-                if ((meta.x & (1u << l)) && (pk->masks[l] & rmask)) m |= 1u << l;
+                if ((meta.x & (1u << l)) && ((pk_lds ? pk_l->masks[l] : pk->masks[l]) & rmask)) m |= 1u << l;
             }
             if (m != 0) {
               CRT_PHASE(3)
@@ -423,13 +455,24 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
               r.okx = sel3(g0.x, g0.y, g0.z, kx); r.oky = sel3(g0.x, g0.y, g0.z, ky); r.okz = sel3(g0.x, g0.y, g0.z, kz);
               // primitive ids and the normal-ok bits ride along with the vertex loads: fetched at the point of use they
               // would be up to four more dependent round trips per packet, one per accepted lane
-              const uint4 prim4 = *reinterpret_cast<const uint4 *>(pk->prim);
-              const uint32_t normal_ok = pk->normal_ok;
+              uint4 prim4;
+              uint32_t normal_ok;
+              float4 A_x, A_y, A_z, B_x, B_y, B_z, C_x, C_y, C_z;
+              auto load_packet = [&](const Tri4 *q) {
+                prim4 = *reinterpret_cast<const uint4 *>(q->prim);
+                normal_ok = q->normal_ok;
+                const float4 *pl = reinterpret_cast<const float4 *>(&q->v[0][0][0]);
+                A_x = pl[0 + kx]; A_y = pl[0 + ky]; A_z = pl[0 + kz];
+                B_x = pl[3 + kx]; B_y = pl[3 + ky]; B_z = pl[3 + kz];
+                C_x = pl[6 + kx]; C_y = pl[6 + ky]; C_z = pl[6 + kz];
+              };
+              if (pk_lds) {  // two arms, as for the nodes: merged they become FLAT loads through a generic pointer
+                load_packet(pk_l);
+                asm volatile("" : "+v"(A_x.x), "+v"(B_x.x), "+v"(C_x.x), "+v"(prim4.x));
+              } else {
+                load_packet(pk);
+              }
               const uint32_t prim_of[4] = {prim4.x, prim4.y, prim4.z, prim4.w};
-              const float4 *pl = reinterpret_cast<const float4 *>(&pk->v[0][0][0]);
-              const float4 A_x = pl[0 + kx], A_y = pl[0 + ky], A_z = pl[0 + kz];
-              const float4 B_x = pl[3 + kx], B_y = pl[3 + ky], B_z = pl[3 + kz];
-              const float4 C_x = pl[6 + kx], C_y = pl[6 + ky], C_z = pl[6 + kz];
               const float vax[4] = {A_x.x, A_x.y, A_x.z, A_x.w}, vay[4] = {A_y.x, A_y.y, A_y.z, A_y.w},
                           vaz[4] = {A_z.x, A_z.y, A_z.z, A_z.w};
               const float vbx[4] = {B_x.x, B_x.y, B_x.z, B_x.w}, vby[4] = {B_y.x, B_y.y, B_y.z, B_y.w},
@@ -516,14 +559,15 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
         if (accepted) {
           f0[at(row)].w = closest;
           wr(best, row, B_BU, __float_as_uint(bu)); wr(best, row, B_BV, __float_as_uint(bv)); wr(best, row, B_BDEFER, bdefer);
+          wr(best, row, B_BINST, kInvalid);
           aux |= 1u << level;
         }
         if (occluded) aux |= 1u;
         if (next == PH_PACKET) {
           cursor = k;
         } else if (next == PH_SCALAR) {  // the leaf's packets are done: scalar list, or on to the next entry
-          aux = (aux & 0xffu) | (rem << 8);
           next = advance(row, sp, base, level, rem, cur, cursor);
+          aux = (aux & 0xffu) | (rem << 8);
         }
         W(W_CTL, row) = (c & ~0xffu) | sp;
         W(W_CUR, row) = cur;
@@ -563,9 +607,6 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
 #pragma unroll
                 for (int i = 0; i < 12; i++) w2l[i] = in->w2l[i];
               }
-              Frame &f = frames[row][level];
-              f.ox = g0.x; f.oy = g0.y; f.oz = g0.z; f.dx = dx; f.dy = dy; f.dz = dz;
-              f.cursor = cursor; f.cend = rem; f.base = base; f.inst = inst; f.geom = ih.z; f.has_packets = hp;
               // transform_point3a / transform_vector3a: ((x_axis*v.x + y_axis*v.y) + z_axis*v.z) [+ translation]
               float px = w2l[0] * g0.x, py = w2l[1] * g0.x, pz = w2l[2] * g0.x;
               px = px + w2l[3] * g0.y; py = py + w2l[4] * g0.y; pz = pz + w2l[5] * g0.y;
@@ -576,17 +617,55 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
               qx = qx + w2l[6] * dz; qy = qy + w2l[7] * dz; qz = qz + w2l[8] * dz;
               RayCtx r;
               r.ox = px; r.oy = py; r.oz = pz; r.dx = qx; r.dy = qy; r.dz = qz;  // unnormalised: local t == world t
-              wr(side_d, row, 0, qx); wr(side_d, row, 1, qy); wr(side_d, row, 2, qz);
-              level++;
-              aux &= ~(1u << level);
-              base = sp;
-              cursor = 0;
-              rem = 0;
-              uint32_t kz, swap;
-              store_ray(row, r, (ih.y & 1u) != 0, closest, kz, swap);
-              c = ctl_pack(sp, base, level, ih.y & 1u, kz, swap, 0);
+              // The instanced tree's root node is tested HERE, with the local ray still in registers: the placement's
+              // world box is the box of a transformed box (prim.rs:298-319), so many rays that enter it touch none of
+              // the root's children. Such a visit ends where the reference's ends — Bvh::hit expands the root, finds
+              // no lane, returns None (bvh.rs:455-470) — but without saving a frame, rewriting the ray's LDS state,
+              // a node step and an exit step (each a scheduling round at a third of the lanes) for nothing.
+              bool enter = true;
+              if (CRT_ROOT_REJECT) {
+                const float4 *nb = reinterpret_cast<const float4 *>(&S.nodes[ih.x]);
+                const float4 mnx = nb[0], mny = nb[1], mnz = nb[2], mxx = nb[3], mxy = nb[4], mxz = nb[5];
+                const uint4 ch = *reinterpret_cast<const uint4 *>(nb + 6);
+                const float TINY = 1e-20f, HUGE_ = 1e20f;  // safe_inv3 (bvh.rs:662-668), as setup_ray
+                const float ix = absf(qx) < TINY ? copysgn(HUGE_, qx) : 1.0f / qx;
+                const float iy = absf(qy) < TINY ? copysgn(HUGE_, qy) : 1.0f / qy;
+                const float iz = absf(qz) < TINY ? copysgn(HUGE_, qz) : 1.0f / qz;
+                const float lo_x[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, lo_y[4] = {mny.x, mny.y, mny.z, mny.w},
+                            lo_z[4] = {mnz.x, mnz.y, mnz.z, mnz.w};
+                const float hi_x[4] = {mxx.x, mxx.y, mxx.z, mxx.w}, hi_y[4] = {mxy.x, mxy.y, mxy.z, mxy.w},
+                            hi_z[4] = {mxz.x, mxz.y, mxz.z, mxz.w};
+                const uint32_t child[4] = {ch.x, ch.y, ch.z, ch.w};
+                enter = false;
+#pragma unroll
+                for (int l = 0; l < 4; l++) {  // RaySlab::slab4, bvh.rs:790-808
+                  const float t0x = (lo_x[l] - px) * ix, t1x = (hi_x[l] - px) * ix;
+                  const float t0y = (lo_y[l] - py) * iy, t1y = (hi_y[l] - py) * iy;
+                  const float t0z = (lo_z[l] - pz) * iz, t1z = (hi_z[l] - pz) * iz;
+                  const float tn = fmaxf(fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z)), t_min);
+                  const float tf = fminf(fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)), closest);
+                  enter |= (tn <= tf) && child[l] != kInvalid;
+                }
+              }
               if (STATS) { st.descents++; st.queries[1]++; }
-              push(row, sp, ih.x);
+              if (!enter) {
+                if (STATS) st.nodes[1]++;  // the root visit the reference makes
+              } else {
+                Frame f;
+                f.ox = g0.x; f.oy = g0.y; f.oz = g0.z; f.dx = dx; f.dy = dy; f.dz = dz;
+                f.cursor = cursor; f.cend = rem; f.base = base; f.inst = inst; f.geom = ih.z; f.has_packets = hp;
+                frames[row][level] = f;
+                wr(side_d, row, 0, qx); wr(side_d, row, 1, qy); wr(side_d, row, 2, qz);
+                level++;
+                aux &= ~(1u << level);
+                base = sp;
+                cursor = 0;
+                rem = 0;
+                uint32_t kz, swap;
+                store_ray(row, r, (ih.y & 1u) != 0, closest, kz, swap);
+                c = ctl_pack(sp, base, level, ih.y & 1u, kz, swap, 0);
+                push(row, sp, ih.x);
+              }
             }
           }
         } else {
@@ -618,6 +697,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
                   wr(side_n, row, 2, ((g0.z + root * dz) - s.z) / s.w);
                   wr(side_n, row, 3, __uint_as_float(0u));  // prim_id 0
                   wr(best, row, B_BU, 0); wr(best, row, B_BV, 0); wr(best, row, B_BDEFER, kInvalid); wr(best, row, B_BGEOM, hd.y);
+                  wr(best, row, B_BINST, kInvalid);
                   aux |= 1u << level;
                   if (STATS) st.accepted++;
                 }
@@ -640,6 +720,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
                   closest = t;
                   f0[at(row)].w = t;
                   wr(best, row, B_BU, __float_as_uint(u)); wr(best, row, B_BV, __float_as_uint(v)); wr(best, row, B_BDEFER, pi);
+                  wr(best, row, B_BINST, kInvalid);
                   aux |= 1u << level;
                   if (STATS) st.accepted++;
                 }
@@ -670,7 +751,14 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
         const bool inner_found = (aux >> level) & 1u;
         level--;
         const Frame f = frames[row][level];
-        if (inner_found) {
+        // The instance's normal transform, shared by the exit (nested levels) and emit (deferred) sites: the hit's
+        // normal and primitive id in the instanced scene's space -> normalize(w2l.matrix3^T * n) (prim.rs:327, :360).
+        if (inner_found && CRT_DEFER_NORMAL && level == 0) {
+          // back at the top level: keep the normal where it is (pending triangle or side_n) and remember the instance
+          wr(best, row, B_BINST, f.inst); wr(best, row, B_BGEOM, f.geom);
+          aux |= 1u;
+          if (STATS) st.accepted++;
+        } else if (inner_found) {
           float bnx, bny, bnz;
           uint32_t bprim;
           const uint32_t bdefer = rd(best, row, B_BDEFER);
@@ -681,28 +769,12 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
             bnx = rd(side_n, row, 0); bny = rd(side_n, row, 1); bnz = rd(side_n, row, 2);
             bprim = __float_as_uint(rd(side_n, row, 3));
           }
-          const DevInstance *in = &S.instances[f.inst];
-          float nm[9];
-          if ((in->flags & 2u) && time > 0.0f) {
-            float w2l[12];
-            motion_w2l(*in, time, w2l);
-            // normal matrix = w2l.matrix3 transposed (prim.rs:327)
-            nm[0] = w2l[0]; nm[1] = w2l[3]; nm[2] = w2l[6];
-            nm[3] = w2l[1]; nm[4] = w2l[4]; nm[5] = w2l[7];
-            nm[6] = w2l[2]; nm[7] = w2l[5]; nm[8] = w2l[8];
-          } else {
-            nm[0] = in->w2l[0]; nm[1] = in->w2l[3]; nm[2] = in->w2l[6];  // cached normal matrix = w2l.matrix3 transposed
-            nm[3] = in->w2l[1]; nm[4] = in->w2l[4]; nm[5] = in->w2l[7];
-            nm[6] = in->w2l[2]; nm[7] = in->w2l[5]; nm[8] = in->w2l[8];
-          }
-          float x = nm[0] * bnx, y = nm[1] * bnx, z = nm[2] * bnx;
-          x = x + nm[3] * bny; y = y + nm[4] * bny; z = z + nm[5] * bny;
-          x = x + nm[6] * bnz; y = y + nm[7] * bnz; z = z + nm[8] * bnz;
-          const float len = sqrtf(dot3(x, y, z, x, y, z));
-          wr(side_n, row, 0, x / len); wr(side_n, row, 1, y / len); wr(side_n, row, 2, z / len);
+          instance_normal(S.instances[f.inst], time, bnx, bny, bnz);
+          wr(side_n, row, 0, bnx); wr(side_n, row, 1, bny); wr(side_n, row, 2, bnz);
           wr(side_n, row, 3, __uint_as_float(bprim));
           // the hit is attributed to the instance's geometry id; prim_id stays the inner one
           wr(best, row, B_BDEFER, kInvalid); wr(best, row, B_BGEOM, f.geom);
+          wr(best, row, B_BINST, kInvalid);
           aux |= 1u << level;
           if (STATS) st.accepted++;
         }
@@ -712,7 +784,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
         uint32_t kz, swap;
         store_ray(row, r, f.has_packets != 0, closest, kz, swap);
         uint32_t cursor = f.cursor;
-        const uint32_t rem = f.cend;
+        uint32_t rem = f.cend;
         next = advance(row, sp, f.base, level, rem, cur, cursor);
         W(W_CTL, row) = ctl_pack(sp, f.base, level, f.has_packets ? 1u : 0u, kz, swap, 0);
         W(W_CUR, row) = cur;
@@ -739,6 +811,11 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
           } else {
             hit.nx = rd(side_n, row, 0); hit.ny = rd(side_n, row, 1); hit.nz = rd(side_n, row, 2);
             hit.geom = rd(best, row, B_BGEOM); hit.prim = __float_as_uint(rd(side_n, row, 3));
+          }
+          const uint32_t binst = rd(best, row, B_BINST);
+          if (CRT_DEFER_NORMAL && binst != kInvalid) {  // the hit lies in a level-1 instance: its normal is still local
+            instance_normal(S.instances[binst], rd(side_d, row, 3), hit.nx, hit.ny, hit.nz);
+            hit.geom = rd(best, row, B_BGEOM);  // the instance's geometry id; prim_id stays the inner one
           }
         }
         // the ray's own direction: back in side_d once every instance frame has been left (closest-hit rays only
@@ -778,9 +855,15 @@ __device__ __forceinline__ void run_traversal(const DevScene &S, uint32_t *lds, 
   const int pnodes = pstack == (uint32_t)kPoolStackDeep ? kPoolNodesDeep : kPoolNodes;
   const int wave_dwords = pool_lds_dwords<CRT_POOL_ROWS>((int)pstack);
   uint32_t *lds_nodes = lds + (kBlock / 64) * wave_dwords;
-  const uint32_t n_lds = stage_nodes(S, lds_nodes, pnodes);  // ends with a barrier
-  traverse_pool<ANY, STATS, CRT_POOL_ROWS>(S, lds + (threadIdx.x >> 6) * wave_dwords, t_min, lds_nodes, n_lds, pstack, err,
-                                           st, fetch, emit);
+  uint32_t n_lds_pk;
+  const uint32_t n_lds = stage_nodes(S, lds_nodes, pnodes, n_lds_pk);  // ends with a barrier
+  // Two instantiations, chosen by the scene (uniform): flat scenes run the engine that knows nothing of direct leaf
+  // words — carrying the direct form's extra state through the node loop costs the bench scene 2 % (profiles/README.md).
+  uint32_t *wave_lds = lds + (threadIdx.x >> 6) * wave_dwords;
+  if (CRT_DIRECT_LEAVES != 0 && S.direct_leaves != 0)
+    traverse_pool<ANY, STATS, CRT_POOL_ROWS, true>(S, wave_lds, t_min, lds_nodes, n_lds, n_lds_pk, pstack, err, st, fetch, emit);
+  else
+    traverse_pool<ANY, STATS, CRT_POOL_ROWS, false>(S, wave_lds, t_min, lds_nodes, n_lds, n_lds_pk, pstack, err, st, fetch, emit);
 }
 
 }  // namespace dev

@@ -313,10 +313,19 @@ int Scene::ensure_device() {
   }
   // Device form of a node's child words: leaf children carry the leaf tag (bit 31), empty lanes are CRT_INVALID_ID,
   // so the traversal derives everything from the word it has to load anyway and never touches `flags`.
+  bool direct = f.instances.size() >= 64 || f.packets.empty();
+  if (const char *e = getenv("CRT_DIRECT_LEAVES")) direct = atoi(e) != 0;  // A/B runs
+  if (!CRT_DIRECT_LEAVES) direct = false;  // an engine built without the direct form must never meet one
   for (WideNode &n : f.nodes)
     for (int l = 0; l < 4; l++) {
       if (!(n.flags & (1u << l))) n.child[l] = CRT_INVALID_ID;
-      else if (n.flags & (1u << (4 + l))) n.child[l] |= 0x80000000u;
+      else if (n.flags & (1u << (4 + l))) {
+        const Leaf &lf = f.leaves[n.child[l]];
+        if (direct && lf.pkt_count == 0 && lf.idx_count >= 1 && lf.idx_count <= 3 && lf.idx_first < (1u << 28))
+          n.child[l] = 0x80000000u | kDirectLeafTag | (lf.idx_count << 28) | lf.idx_first;
+        else
+          n.child[l] |= 0x80000000u;
+      }
     }
   auto img = std::make_unique<DeviceImage>();
   const size_t sz[7] = {f.nodes.size() * sizeof(WideNode), f.leaves.size() * sizeof(Leaf),
@@ -350,6 +359,8 @@ int Scene::ensure_device() {
   img->view.root = me.root;
   img->view.has_packets = me.has_packets;
   img->view.n_nodes = uint32_t(f.nodes.size());
+  img->view.n_packets = uint32_t(f.packets.size());
+  img->view.direct_leaves = direct ? 1u : 0u;
   // kernels/traverse_pool.hip.h: the engine's LDS split. Deep stacks pay where rays spend their time inside
   // instances (thousands of placements); a handful of placements under a real top-level tree is still a flat scene.
   img->view.pool_stack = f.instances.size() >= 64 ? 10u : 6u;

@@ -263,6 +263,11 @@ size_t crt_renderer_active_pixels(const CrtRenderer *r);
 int crt_renderer_sample_counts(CrtRenderer *r, uint32_t *host_out);
 /* Counters since the last clear (syncs the stream the batches ran on). */
 int crt_render_stats(CrtRenderer *r, CrtRayStats *out);
+/* Diagnostic for shade's material-class partition: while enabled (enable = 1 / 0; -1 leaves it as is) the vertex step
+ * counts, per material class (0 emissive / escaped, 1 base, 2 coat-fuzz-thin-film, 3 transmissive-subsurface), the wave
+ * executions that contained a vertex of the class and how many of their 64 lanes held one. out_* (both or neither):
+ * the counts since the last read, which also clears them. lanes / (64 * waves) is the class's lane utilisation. */
+int crt_renderer_shade_class_stats(CrtRenderer *r, int enable, uint64_t out_waves[4], uint64_t out_lanes[4]);
 /* Live HIP-event timing of the kernels launched by crt_render_samples since the last reset, by class:
  * 0 = extend (closest-hit traversal) — or, by default, the fused path-loop kernel that runs generate, extend, shade
  * and shadow of a whole batch in one launch (environment CRT_FUSED=0 launches every stage separately) —
