@@ -34,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2  # wave64 VALU instructions/s: 256 CUs x 4 SIMD-32, one instruction per 2 cycles at 2.4 GHz
 
 
 def main():
@@ -178,16 +179,37 @@ def main():
             del r2
         finally:
             os.environ["CRT_FUSED"] = "1"
+    # Measured counters of the same kernel, from the committed PMC passes IF they are of this build and workload.
+    workload_key = "%s %dx%d %dspp" % (args.scene, args.width, args.height, spp_step)
+    pmc, pmc_note = _pmc_for(workload_key, fused) if world == 1 else (None, "N > 1")
+    avg_s = (k_ms / max(k_n, 1)) * 1e-3
+    traffic = hbm_frac = l2_hit = valu_issue = None
+    if pmc and avg_s > 0:
+        traffic = int(pmc["ea_dram_read_bytes_per_launch"] + pmc["ea_dram_write_bytes_per_launch"])
+        hbm_frac = round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4)
+        l2_hit = round(pmc["l2_hit_rate"], 4)
+        # wave64 VALU instructions per second against the SIMDs' issue ceiling: CUs x 4 SIMD-32 x clock / 2 cycles
+        valu_issue = round(pmc["valu_insts_per_launch"] / avg_s / (VALU_ISSUE_PEAK), 4)
     roofline = {
         "kernel": "k_path (one launch per batch: generate + BVH4 traversal + shading + shadow per queue segment)" if fused
                   else "k_extend (BVH4 closest-hit traversal)",
+        # `achieved` / `frac` are the task's definition: ALGORITHMIC bytes over kernel time against the HBM
+        # peak. On this cache-resident scene most of those bytes never leave LDS / L1 / L2 — the physical picture is in
+        # the measured fields below: fabric-side traffic is a fraction of the peak and the SIMDs issue at about a third
+        # of their ceiling; the kernel is bound by dependent-load latency at 3 waves per SIMD, not by HBM.
         "bound": "hbm",
         "achieved": round(achieved, 2),
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5),
-        # the committed PMC passes were taken on the default workload only
-        "traffic": _traffic_from_profile(fused) if (args.scene == "cornellbox" and (args.width, args.height) == (1920, 1080)) else None,
+        "algorithmic_gb_s": round(achieved, 2),
+        "traffic": traffic,                    # measured L2<->fabric bytes per launch (TCC_EA0_*_DRAM_32B x 32 B), or null
+        "hbm_measured_frac": hbm_frac,         # traffic / launch time / 8 TB/s
+        "l2_hit": l2_hit,
+        "valu_issue_frac": valu_issue,
+        "physical_bound": "dependent-load latency at 3 waves/SIMD (see hbm_measured_frac, valu_issue_frac)" if pmc else None,
+        "pmc_source": pmc_note,
+        "kernel_source_hash": kernel_source_hash(),
         "launches": k_n,
         "avg_launch_ms": round(k_ms / max(k_n, 1), 5),
         "bytes_per_launch": int(per_launch),
@@ -262,16 +284,50 @@ def _self_launch(n):
     return res.returncode if res.returncode else (0 if lines else 1)
 
 
-def _traffic_from_profile(fused):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes, or null."""
-    p = os.path.join(ROOT, "profiles", "r01_pmc_path.json" if fused else "r01_pmc_extend.json")
-    if os.path.exists(p):
-        try:
-            with open(p) as f:
-                return json.load(f).get("hbm_bytes_per_launch")
-        except Exception:
-            return None
-    return None
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) over the native sources the kernels are built from (crust-render_amd/csrc: *.cpp,
+    *.h, kernels/*, Makefile) — the key that ties a committed PMC profile to the build it was taken on."""
+    import hashlib
+    base = os.path.join(ROOT, "crust-render_amd", "csrc")
+    files = []
+    for d, _dirs, names in os.walk(base):
+        if os.path.basename(d).startswith("_obj"):
+            continue
+        for n in names:
+            if n.endswith((".cpp", ".h", ".hip", "Makefile")):
+                files.append(os.path.join(d, n))
+    h = hashlib.sha256()
+    for f in sorted(files):
+        h.update(os.path.relpath(f, base).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc_bench.json")
+
+
+def _pmc_for(workload_key, fused):
+    """The committed rocprofv3 --pmc passes for this workload (profiles/r02_pmc_bench.json, written by
+    profiles/summarize_pmc_bench.py) — but only if they were taken on THIS build: the file carries the kernel source
+    hash of the build it profiled, and a profile of other sources says nothing about the kernel being timed now.
+    Returns (entry or None, note)."""
+    if not fused:
+        return None, "PMC passes exist for the fused kernel only"
+    if not os.path.exists(PMC_PROFILE):
+        return None, "no PMC profile committed"
+    try:
+        with open(PMC_PROFILE) as f:
+            prof = json.load(f)
+    except Exception as e:  # noqa: BLE001
+        return None, "unreadable PMC profile: %s" % e
+    here = kernel_source_hash()
+    if prof.get("kernel_source_hash") != here:
+        return None, "PMC profile is of build %s, this build is %s: traffic not reported" % (prof.get("kernel_source_hash"), here)
+    e = prof.get("workloads", {}).get(workload_key)
+    if e is None:
+        return None, "no PMC passes for workload %r" % workload_key
+    return e, "profiles/r02_pmc_bench.json (git %s)" % prof.get("git_commit", "?")
 
 
 def _cpu_baseline(crt, desc, args):

@@ -623,7 +623,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
               // no lane, returns None (bvh.rs:455-470) — but without saving a frame, rewriting the ray's LDS state,
               // a node step and an exit step (each a scheduling round at a third of the lanes) for nothing.
               bool enter = true;
-              if (CRT_ROOT_REJECT) {
+              if (CRT_ROOT_REJECT && DIRECT) {  // the instance-heavy engine only: on cornellbox (two placements) the test costs 1.5 % and rejects little
                 const float4 *nb = reinterpret_cast<const float4 *>(&S.nodes[ih.x]);
                 const float4 mnx = nb[0], mny = nb[1], mnz = nb[2], mxx = nb[3], mxy = nb[4], mxz = nb[5];
                 const uint4 ch = *reinterpret_cast<const uint4 *>(nb + 6);
@@ -841,7 +841,10 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
 #define CRT_POOL_NODES 72
 #endif
 constexpr int kPoolNodes = CRT_POOL_NODES;  // nodes of the top of the tree staged in LDS per workgroup (flat scenes)
-constexpr int kPoolNodesDeep = 2;           // ... with the deep stack
+#ifndef CRT_POOL_NODES_DEEP
+#define CRT_POOL_NODES_DEEP 16
+#endif
+constexpr int kPoolNodesDeep = CRT_POOL_NODES_DEEP;  // ... with the deep stack: 16 still fit three workgroups per CU (+0.4 %); 24 do not (-33 %)
 constexpr int kEngineLdsFlat = (kBlock / 64) * pool_lds_dwords<CRT_POOL_ROWS>(kPoolStack) + kPoolNodes * kLdsNodeStride;
 constexpr int kEngineLdsDeep = (kBlock / 64) * pool_lds_dwords<CRT_POOL_ROWS>(kPoolStackDeep) + kPoolNodesDeep * kLdsNodeStride;
 constexpr int kEngineLdsDwords = kEngineLdsFlat > kEngineLdsDeep ? kEngineLdsFlat : kEngineLdsDeep;
@@ -857,8 +860,10 @@ __device__ __forceinline__ void run_traversal(const DevScene &S, uint32_t *lds, 
   uint32_t *lds_nodes = lds + (kBlock / 64) * wave_dwords;
   uint32_t n_lds_pk;
   const uint32_t n_lds = stage_nodes(S, lds_nodes, pnodes, n_lds_pk);  // ends with a barrier
-  // Two instantiations, chosen by the scene (uniform): flat scenes run the engine that knows nothing of direct leaf
-  // words — carrying the direct form's extra state through the node loop costs the bench scene 2 % (profiles/README.md).
+  // Two instantiations, chosen by the scene (uniform, DevScene::direct_leaves: instance-heavy or packet-free scenes):
+  // the DIRECT engine reads direct leaf words and tests an instanced tree's root at entry; flat scenes run the engine
+  // that knows nothing of either — carrying the direct form's state through the node loop costs the bench scene 2 %,
+  // the root test 1.5 % (profiles/README.md).
   uint32_t *wave_lds = lds + (threadIdx.x >> 6) * wave_dwords;
   if (CRT_DIRECT_LEAVES != 0 && S.direct_leaves != 0)
     traverse_pool<ANY, STATS, CRT_POOL_ROWS, true>(S, wave_lds, t_min, lds_nodes, n_lds, n_lds_pk, pstack, err, st, fetch, emit);

@@ -9,6 +9,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <unordered_map>
 
@@ -328,14 +329,15 @@ int Scene::ensure_device() {
       }
     }
   auto img = std::make_unique<DeviceImage>();
-  const size_t sz[7] = {f.nodes.size() * sizeof(WideNode), f.leaves.size() * sizeof(Leaf),
-                        f.packets.size() * sizeof(Tri4),   f.indices.size() * sizeof(uint32_t),
-                        f.prims.size() * sizeof(DevPrim),  f.instances.size() * sizeof(DevInstance),
-                        f.normals.size() * sizeof(float)};
-  const void *src[7] = {f.nodes.data(), f.leaves.data(), f.packets.data(), f.indices.data(),
-                        f.prims.data(), f.instances.data(), f.normals.data()};
-  size_t off[7], total = 0;
-  for (int i = 0; i < 7; i++) {
+  constexpr int NA = 7;
+  const size_t sz[NA] = {f.nodes.size() * sizeof(WideNode), f.leaves.size() * sizeof(Leaf),
+                         f.packets.size() * sizeof(Tri4),   f.indices.size() * sizeof(uint32_t),
+                         f.prims.size() * sizeof(DevPrim),  f.instances.size() * sizeof(DevInstance),
+                         f.normals.size() * sizeof(float)};
+  const void *src[NA] = {f.nodes.data(), f.leaves.data(), f.packets.data(), f.indices.data(),
+                         f.prims.data(), f.instances.data(), f.normals.data()};
+  size_t off[NA], total = 0;
+  for (int i = 0; i < NA; i++) {
     off[i] = total;
     total += (sz[i] + 255) & ~size_t(255);  // every array starts on a 256-byte boundary
     img->bytes[i] = sz[i];
@@ -345,7 +347,7 @@ int Scene::ensure_device() {
   if (!CRT_HIP_OK(hipMalloc(&img->blob, total))) return CRT_ERR_NO_DEVICE;
   if (!CRT_HIP_OK(hipMemset(static_cast<char *>(img->blob) + err_off, 0, 256))) return CRT_ERR_NO_DEVICE;
   img->err = reinterpret_cast<uint32_t *>(static_cast<char *>(img->blob) + err_off);
-  for (int i = 0; i < 7; i++)
+  for (int i = 0; i < NA; i++)
     if (sz[i] && !CRT_HIP_OK(hipMemcpy(static_cast<char *>(img->blob) + off[i], src[i], sz[i], hipMemcpyHostToDevice)))
       return CRT_ERR_NO_DEVICE;
   char *base = static_cast<char *>(img->blob);
