@@ -202,3 +202,35 @@ def test_render_report_counts_the_scene_and_the_rays(crt, tmp_path):
         assert needle in text, needle
     back = crt.exr.read_exr(out)
     assert np.array_equal(np.ascontiguousarray(back[::-1], dtype=np.float32).view(np.uint32), img.view(np.uint32))
+
+
+def test_shade_class_partition_keeps_waves_pure_and_bits_unchanged(crt):
+    """Shade's material-class partition (north_star: per-material sorting on wave primitives): with it the vertex step's
+    waves hold one class each — lane utilisation of every class that occurs is far above the natural mix's — and the
+    image and counters are the ones the unpartitioned path (CRT_PARTITION=0) produces (which the other tests of this file
+    compare with the oracle). 960x540 x 16 spp: segments long enough (11 000 paths per workgroup) for full rings."""
+    import subprocess
+    import sys
+    import json
+    code = (
+        "import os, sys, json, numpy as np; sys.path.insert(0, %r); import torch\n"
+        "from __graft_entry__ import load_package; crt = load_package()\n"
+        "r, _ = crt.load_usda(os.path.join(%r, 'scenes', 'openpbr_showcase.usda'), 960, 540, 12)\n"
+        "r.shade_class_stats(True); r.render_samples(0, 16); torch.cuda.synchronize(); st = r.stats()\n"
+        "np.save(sys.argv[1], r.image())\n"
+        "print(json.dumps(dict(stats=[st.closest_hit, st.shadow_rays, st.vertices, st.rr_killed], cls=r.shade_class_stats())))\n" % (ROOT, ROOT))
+    out = {}
+    for part in ("0", "1"):
+        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "crt_part%s.npy" % part)
+        res = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, CRT_PARTITION=part), capture_output=True,
+                             text=True, timeout=300)
+        assert res.returncode == 0, res.stderr[-2000:]
+        out[part] = (np.load(path), json.loads(res.stdout.strip().splitlines()[-1]))
+    assert out["0"][1]["stats"] == out["1"][1]["stats"]
+    assert np.array_equal(out["0"][0].view(np.uint32), out["1"][0].view(np.uint32))
+    mixed, pure = out["0"][1]["cls"], out["1"][1]["cls"]
+    seen = [k for k, (w, u) in pure.items() if w > 0]
+    assert len(seen) >= 3, pure  # the showcase holds emissive lights, base, layered and transmissive looks
+    for k in seen:
+        assert pure[k][1] > mixed[k][1], (k, pure[k], mixed[k])
+    assert min(pure[k][1] for k in seen) > 0.5 and pure["base"][1] > 0.95
