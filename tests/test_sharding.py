@@ -55,3 +55,40 @@ def test_two_rank_gather_reassembles_the_frame_gloo(tmp_path):
     for r in range(2):
         got = np.load(os.path.join(str(tmp_path), f"frame{r}.npy"))
         assert np.array_equal(got, want)
+
+
+def _worker_gather_to_root(rank, world, port, out_dir, w, h):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
+    crt = load_package()
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    idx = crt.shard.shard_pixels(w, h, rank, world)
+    film = torch.from_numpy(np.stack([idx * 0.25, idx + 0.5, idx * -2.0], axis=1).astype(np.float32))
+    plan = crt.shard.GatherPlan(w, h, world, "cpu")
+    frame = plan.gather(film, dist, dst=0)  # bench.py's collective: a gather to rank 0 only
+    assert (frame is None) == (rank != 0)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "frame_root.npy"), frame.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,w,h", [(4, 1920, 1080), (8, 200, 120)])
+def test_gather_to_rank0_reassembles_uneven_shards_gloo(tmp_path, world, w, h):
+    """The driver's multi-GPU run in miniature: `world` ranks own round-robin 16x16 tiles of a frame whose tile count
+    does not divide evenly (1920x1080: 120 x 68 = 8160 tiles with a 1080 = 67.5 x 16 ragged last row), pad to the
+    largest shard, ONE gather to rank 0, which scatters every shard back to its pixels."""
+    import torch.multiprocessing as mp
+    port = 29600 + (os.getpid() % 2000) + world
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker_gather_to_root, args=(r, world, port, str(tmp_path), w, h)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    i = np.arange(w * h)
+    want = np.stack([i * 0.25, i + 0.5, i * -2.0], axis=1).astype(np.float32)
+    assert np.array_equal(np.load(os.path.join(str(tmp_path), "frame_root.npy")), want)
