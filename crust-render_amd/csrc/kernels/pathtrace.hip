@@ -411,10 +411,17 @@ __global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_extend(Params P, P
 // ---- shade: one iteration of trace_path's loop body for every live path (tracer.rs:1118-1530) ----
 // MEDIA: some material of the scene has an interior medium; scenes without one run the leaner instance (the medium
 // code costs k_shade 80 spilled VGPRs at three waves per SIMD).
-template <bool MEDIA, bool INF>
+// LIT: the light list is not empty. Unlit scenes (cornellbox, the bench scene: sky only) run an instance without the
+// light-sampling block, its second BSDF evaluation, the emitter MIS weights and the previous-vertex plane — code they
+// never execute, but whose registers and scalar constants the fused kernel otherwise carries through every bounce
+// (cornellbox +1.3 %, MedCity +2 %, profiles/README.md). With lights present the strategy is checked at run time.
+// MATS: what the scene's material table holds — 0 simple (no coat, fuzz, thin film, transmission, subsurface anywhere:
+// the OpenPBR code is instantiated without those arms, shade.hip.h), 1 general, 2 general with interior media.
+template <int MATS, bool INF, bool LIT>
 __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S, const PathSoA &N, const HitSoA &H,
                                               const ShadowSoA &Q, Counters *C, int cur, float4 *staging,
                                               uint32_t *sobol_tab /* kArenaDwords: Sobol tables, then the material table */) {
+  constexpr bool MEDIA = MATS == 2, SIMPLE = MATS == 0;
   __shared__ uint32_t lds_ctr[10];  // [1] shadow requests, [2..8] statistics
   __shared__ uint32_t out_n[kBins];  // survivors per direction bin
   __shared__ uint32_t pre[kBins + 1];
@@ -441,6 +448,7 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
     __syncthreads();
   }
   const uint32_t seg0 = blockIdx.x * P.seg_cap;  // shadow queue: one unbinned segment per workgroup
+  const uint32_t n_lights = LIT ? P.n_lights : 0u;
   uint32_t s_closest = 0, s_shadow = 0, s_vertices = 0, s_rr_t = 0, s_rr_k = 0, s_esc = 0, s_depth = 0;
   // Two kinds of work per path: a ray that escaped just adds the sky and ends (cheap), everything else runs the full
   // vertex (expensive). Mixed in one wave the escaped lanes would idle through the vertex code — a third of the
@@ -593,11 +601,11 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
       // sample, i.e. where eval is available, so the "eval is None" arm reduces to the delta flag.
       auto emission_weight = [&]() -> float {
         if (prev_delta) return 1.0f;
-        for (uint32_t k = 0; k < P.n_lights; k++) {  // LightList::find_by_geom, light.rs:436-440
+        for (uint32_t k = 0; k < n_lights; k++) {  // LightList::find_by_geom, light.rs:436-440
           if (P.lights[k].geom_id == geom) {
             const float4 E = S.e[i];
             const V3 from = v3(E.x, E.y, E.z);
-            const float light_pdf = rmax(solid_angle_pdf(P.lights[k], from, rec.p) / (float)P.n_lights, 1e-6f);
+            const float light_pdf = rmax(solid_angle_pdf(P.lights[k], from, rec.p) / (float)n_lights, 1e-6f);
             return bounce_weight(P.strategy, E.w, light_pdf);
           }
         }
@@ -611,7 +619,7 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
           if (has_hit) {
             const CrtMaterial &mat = mats[geom];
             const float cos_o = fabs_(dot(normalize(rd), rec.normal));
-            V3 emitted = mat_emitted_directional(mat, cos_o);
+            V3 emitted = mat_emitted_directional<SIMPLE>(mat, cos_o);
             if (len2(emitted) > 0.0f) {
               if (MEDIA && med.present) emitted = emitted * medium_transmittance(med, rec.t);  // tracer.rs:1134-1136
               L = L + beta * (emitted * emission_weight());
@@ -653,7 +661,7 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
         } else if (!has_hit) {  // tracer.rs:1321-1342 (rays that carried a medium out of the scene end here)
           s_esc++;
           const V3 unit_direction = normalize(rd);
-          const V3 background = INF ? escaped_background(P.lights, P.n_lights, P.strategy, unit_direction,
+          const V3 background = INF ? escaped_background(P.lights, n_lights, P.strategy, unit_direction,
                                                         prev_valid && !prev_delta, S.e[i].w)
                                     : splat(0.0f) + sky_gradient(unit_direction);
           L = L + beta * background;
@@ -664,7 +672,7 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
           V3 atten = splat(1.0f);
           if (MEDIA && med.present) atten = splat(1.0f) * (med.scattering ? medium_chromatic(med, rec.t) : medium_transmittance(med, rec.t));
           const float cos_o = fabs_(dot(normalize(rd), rec.normal));
-          const V3 emitted = mat_emitted_directional(mat, cos_o);
+          const V3 emitted = mat_emitted_directional<SIMPLE>(mat, cos_o);
           V3 emit_here = splat(0.0f);
           if (prev_valid) {  // tracer.rs:1372-1381
             if (len2(emitted) > 0.0f) L = L + beta * ((atten * emitted) * emission_weight());
@@ -674,11 +682,11 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
           const V3 ba = beta * atten;
 
           // === 1. direct lighting by light sampling (tracer.rs:1394-1445) ===
-          if (P.strategy != CRT_STRATEGY_BSDF && P.n_lights > 0) {
+          if (LIT && P.strategy != CRT_STRATEGY_BSDF && n_lights > 0) {
             float nee_s[4];
             draw_sample4(new_domain(vdom, K_NEE), nee_s, sobol_tab);
-            uint32_t li = (uint32_t)(nee_s[0] * (float)P.n_lights);  // LightList::pick, light.rs:421-429
-            if (li > P.n_lights - 1) li = P.n_lights - 1;
+            uint32_t li = (uint32_t)(nee_s[0] * (float)n_lights);  // LightList::pick, light.rs:421-429
+            if (li > n_lights - 1) li = n_lights - 1;
             const CrtLight &light = P.lights[li];
             LightSample ls;
             if (light_sample_li<INF>(light, rec.p, nee_s[1], nee_s[2], ls)) {
@@ -687,10 +695,10 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
               sh_d = ls.direction;
               sh_tmax = ls.distance - 0.001f;
               const float cosine = fabs_(dot(rec.normal, ls.direction));
-              const float light_pdf = rmax(ls.pdf / (float)P.n_lights, 1e-6f);
+              const float light_pdf = rmax(ls.pdf / (float)n_lights, 1e-6f);
               V3 brdf_value; float brdf_pdf;
               V3 nee = splat(0.0f);
-              if (mat_eval(mat, rd, rec, ls.direction, brdf_value, brdf_pdf)) {
+              if (mat_eval<SIMPLE>(mat, rd, rec, ls.direction, brdf_value, brdf_pdf)) {
                 const float weight = light_weight(P.strategy, light_pdf, brdf_pdf);
                 V3 c = (ls.radiance * brdf_value) * cosine;
                 c = c * splat(1.0f);  // shadow_tr == ONE when unoccluded
@@ -703,7 +711,7 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
 
           // === 2. indirect lighting by BSDF sampling (tracer.rs:1459-1523) ===
           Scatter sample;
-          if (mat_scatter(mat, rd, rec, new_domain(vdom, K_BSDF), sample, sobol_tab)) {
+          if (mat_scatter<SIMPLE>(mat, rd, rec, new_domain(vdom, K_BSDF), sample, sobol_tab)) {
             const V3 dir = normalize(sample.dir);
             const float cosine = sample.delta ? 1.0f : fabs_(dot(rec.normal, dir));
             const V3 factor = (sample.value * cosine) / sample.pdf;
@@ -752,7 +760,7 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
       st_nt(&N.c[j], make_float4(beta.z, L.x, L.y, L.z));
       st_nt(&N.d[j], make_uint4(pattern, pix, ((meta & 0xffffu) + 1u) | (((meta >> 16) - 1u) << 16),
                                 sl | (n_prev_valid ? kPrevValid : 0u) | (n_delta ? kPrevDelta : 0u) | (n_med << kMediumShift)));
-      if (P.n_lights) st_nt(&N.e[j], make_float4(hit_p.x, hit_p.y, hit_p.z, n_ppdf));
+      if (n_lights) st_nt(&N.e[j], make_float4(hit_p.x, hit_p.y, hit_p.z, n_ppdf));
       if (P.has_motion) st_nt(&N.time[j], time);
     } else if (active) {
       st_nt(&staging[film_idx], make_float4(L.x, L.y, L.z, 0.0f));
@@ -779,11 +787,11 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
   if (threadIdx.x >= 1 && threadIdx.x <= 7 && lds_ctr[threadIdx.x + 1])
     atomicAdd(&C->stats[threadIdx.x], (unsigned long long)lds_ctr[threadIdx.x + 1]);
 }
-template <bool MEDIA, bool INF>
+template <int MATS, bool INF>
 __global__ __launch_bounds__(kBlock, CRT_SHADE_WAVES) void k_shade(Params P, PathSoA S, PathSoA N, HitSoA H, ShadowSoA Q, Counters *C,
                                                   int cur, float4 *staging) {
   __shared__ uint32_t sobol_tab[kArenaDwords];
-  shade_segment<MEDIA, INF>(P, S, N, H, Q, C, cur, staging, sobol_tab);
+  shade_segment<MATS, INF, true>(P, S, N, H, Q, C, cur, staging, sobol_tab);
 }
 
 // ---- shadow: World::occluded (rt_world.rs:235-237) for the queue; unoccluded requests pay out ----
@@ -838,7 +846,7 @@ __global__ __launch_bounds__(kBlock, CRT_SHADOW_WAVES) void k_shadow(Params P, P
 // barrier separates the stages: no grid-wide barrier, no launch per bounce, and workgroups drift apart freely — while
 // one is shading (VALU-bound) its neighbours on the same SIMDs are traversing (latency-bound). A workgroup leaves as
 // soon as its segment is empty. LIT: the scene has lights and the strategy samples them (shadow stage present). ----
-template <bool MEDIA, bool LIT, bool INF>
+template <int MATS, bool LIT, bool INF>
 __global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_path(Params P, PathSoA S0, PathSoA S1, HitSoA H, ShadowSoA Q, Counters *C,
                                                  float4 *staging, uint32_t sample_begin, uint32_t n_samples) {
   __shared__ __attribute__((aligned(16))) uint32_t arena[kArenaDwords];
@@ -851,7 +859,7 @@ __global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_path(Params P, Pat
     const PathSoA &N = cur ? S0 : S1;
     extend_segment<false>(P, S, H, C, cur, it == 0 ? 1 : 0, nullptr, arena);
     __syncthreads();  // hit records of this segment are complete; the arena changes hands
-    shade_segment<MEDIA, INF>(P, S, N, H, Q, C, cur, staging, arena);
+    shade_segment<MATS, INF, LIT>(P, S, N, H, Q, C, cur, staging, arena);
     __syncthreads();
     if (LIT) {
       shadow_segment<false>(P, N, Q, C, staging, nullptr, arena);
@@ -968,6 +976,7 @@ struct Renderer {
   uint8_t *d_mat_class = nullptr;  // material_class() per geom_id
   DevMedium *d_media = nullptr;  // [n_materials] by geom_id, then [n_materials] by compact id
   bool has_media = false;
+  int mats_kind = 1;  // 0 simple / 1 general / 2 general with interior media: which instance of the shading code runs
   // adaptive stopping (variance_threshold > 0): per-pixel luminance statistics, sample counts and the active list
   PixelStats *d_pstats = nullptr;
   uint32_t *d_state = nullptr, *d_active = nullptr, *d_count = nullptr;
@@ -1088,21 +1097,25 @@ struct Renderer {
       n_act = h;
       return CRT_OK;
     };
-    const bool lit = P.n_lights > 0 && P.strategy != CRT_STRATEGY_BSDF;
+    const bool lit = P.n_lights > 0;  // the kernel instance; whether the strategy samples the lights is checked in shade
     if (fused && !d_tstats) {  // one launch for the whole path loop (class 0 of the profile), then the film fold
       timed(0, st, [&] {
 #define CRT_PATH(M, L, I) \
   hipLaunchKernelGGL((k_path<M, L, I>), dim3(grid), dim3(kBlock), 0, st, p, S[0], S[1], H, Q, C, staging, sample_begin, n_samples)
-        const int variant = (has_media ? 4 : 0) | (lit ? 2 : 0) | (P.has_inf_lights ? 1 : 0);
+        const int variant = mats_kind * 4 + (lit ? 2 : 0) + (P.has_inf_lights ? 1 : 0);
         switch (variant) {
-          case 0: CRT_PATH(false, false, false); break;
-          case 1: CRT_PATH(false, false, true); break;
-          case 2: CRT_PATH(false, true, false); break;
-          case 3: CRT_PATH(false, true, true); break;
-          case 4: CRT_PATH(true, false, false); break;
-          case 5: CRT_PATH(true, false, true); break;
-          case 6: CRT_PATH(true, true, false); break;
-          default: CRT_PATH(true, true, true); break;
+          case 0: CRT_PATH(0, false, false); break;
+          case 1: CRT_PATH(0, false, true); break;
+          case 2: CRT_PATH(0, true, false); break;
+          case 3: CRT_PATH(0, true, true); break;
+          case 4: CRT_PATH(1, false, false); break;
+          case 5: CRT_PATH(1, false, true); break;
+          case 6: CRT_PATH(1, true, false); break;
+          case 7: CRT_PATH(1, true, true); break;
+          case 8: CRT_PATH(2, false, false); break;
+          case 9: CRT_PATH(2, false, true); break;
+          case 10: CRT_PATH(2, true, false); break;
+          default: CRT_PATH(2, true, true); break;
         }
 #undef CRT_PATH
       });
@@ -1115,8 +1128,9 @@ struct Renderer {
       else timed(0, st, [&] { hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kBlock), 0, st, p, S[cur], H, C, cur, it == 0 ? 1 : 0, d_tstats); });
 #define CRT_SHADE(M, I) \
   timed(1, st, [&] { hipLaunchKernelGGL((k_shade<M, I>), dim3(grid), dim3(kBlock), 0, st, p, S[cur], S[1 - cur], H, Q, C, cur, staging); })
-      if (has_media) { if (P.has_inf_lights) CRT_SHADE(true, true); else CRT_SHADE(true, false); }
-      else { if (P.has_inf_lights) CRT_SHADE(false, true); else CRT_SHADE(false, false); }
+      if (mats_kind == 2) { if (P.has_inf_lights) CRT_SHADE(2, true); else CRT_SHADE(2, false); }
+      else if (mats_kind == 1) { if (P.has_inf_lights) CRT_SHADE(1, true); else CRT_SHADE(1, false); }
+      else { if (P.has_inf_lights) CRT_SHADE(0, true); else CRT_SHADE(0, false); }
 #undef CRT_SHADE
       if (P.n_lights > 0 && P.strategy != CRT_STRATEGY_BSDF) {
         if (d_tstats) timed(2, st, [&] { hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(kBlock), 0, st, p, S[1 - cur], Q, C, staging, d_tstats + 1); });
@@ -1244,6 +1258,12 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
     if (d_count) (void)hipFree(d_count);
   }
   if (!ok) { delete R; return nullptr; }
+  {
+    bool simple = true;
+    for (size_t k = 0; k < n_materials; k++) simple = simple && material_class(materials[k]) <= 1;
+    if (const char *e = getenv("CRT_SIMPLE")) simple = simple && atoi(e) != 0;  // CRT_SIMPLE=0: the general instance (A/B, tests)
+    r.mats_kind = r.has_media ? 2 : (simple ? 0 : 1);
+  }
   P.materials = r.d_materials; P.lights = r.d_lights; P.pixel_index = r.d_pixels;
   P.mat_class = r.d_mat_class;
   P.media = r.d_media; P.media_by_id = r.d_media ? r.d_media + n_materials : nullptr;

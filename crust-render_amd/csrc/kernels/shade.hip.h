@@ -266,6 +266,11 @@ __device__ __forceinline__ V3 eval_diffuse(const CrtMaterial &m, V3 v_local, V3 
   return eon_diffuse(rho, m.base_diffuse_roughness, v_local, l_local) * (1.0f - f_avg_diel);
 }
 
+// SIMPLE (here and below): no material of the scene has a coat, fuzz, thin film, transmission or subsurface
+// (material class <= 1 for the whole table, pathtrace.hip). The arms those weights gate are then compiled out — they are
+// never taken, so nothing changes but the kernel: the thin-film Airy sums, the coat passage's pow(), the sheen, rough
+// transmission with dispersion are the largest bodies and the heaviest users of f64 constants in the vertex code.
+template <bool SIMPLE>
 __device__ __forceinline__ V3 eval_specular(const CrtMaterial &m, V3 v_local, V3 l_local, V3 h_local, float ax, float ay) {
   const float n_dot_v = rmax(v_local.z, 1e-4f);
   const float n_dot_l = rmax(l_local.z, 1e-4f);
@@ -280,14 +285,14 @@ __device__ __forceinline__ V3 eval_specular(const CrtMaterial &m, V3 v_local, V3
   if (m.base_metalness < 1.0f) {
     const V3 f0_diel_base = ld3(m.specular_color) * f0_diel_scalar * m.specular_weight;
     V3 f_diel;
-    if (m.thin_film_weight > 0.0f) {
+    if (!SIMPLE && m.thin_film_weight > 0.0f) {
       const V3 f_normal = fresnel_schlick(v_dot_h, f0_diel_base);
       const V3 f_iri = thin_film_fresnel(v_dot_h, outer_ior, m.thin_film_ior, m.specular_ior, tf_thickness_nm);
       f_diel = f_normal * (1.0f - m.thin_film_weight) + f_iri * m.thin_film_weight;
     } else {
       f_diel = fresnel_schlick(v_dot_h, f0_diel_base);
     }
-    if (m.thin_walled && m.transmission_weight > 0.0f) {
+    if (!SIMPLE && m.thin_walled && m.transmission_weight > 0.0f) {
       const float f_phys = fresnel_schlick_scalar(v_dot_h, f0_diel_scalar);
       const float boost = 2.0f / (1.0f + f_phys);
       f_diel = f_diel * (1.0f + (boost - 1.0f) * m.transmission_weight);
@@ -299,7 +304,7 @@ __device__ __forceinline__ V3 eval_specular(const CrtMaterial &m, V3 v_local, V3
     const V3 metal_f0 = ld3(m.base_color) * m.base_weight;
     const V3 f_metal_base = fresnel_f82_tint(v_dot_h, metal_f0, ld3(m.specular_color));
     V3 f_metal;
-    if (m.thin_film_weight > 0.0f) {
+    if (!SIMPLE && m.thin_film_weight > 0.0f) {
       const V3 f_iri = thin_film_fresnel_metal(v_dot_h, outer_ior, m.thin_film_ior, metal_f0, tf_thickness_nm);
       f_metal = f_metal_base * (1.0f - m.thin_film_weight) + f_iri * m.thin_film_weight;
     } else {
@@ -336,8 +341,9 @@ __device__ __forceinline__ V3 coat_passage(const CrtMaterial &m, float cos_theta
   const float f_coat = fresnel_schlick_scalar(cos_i, f0_from_ior(m.coat_ior));
   return absorb * (1.0f - m.coat_weight * f_coat);
 }
+template <bool SIMPLE>
 __device__ __forceinline__ V3 coat_attenuation(const CrtMaterial &m, float cos_v, float cos_l) {
-  if (m.coat_weight <= 0.0f) return splat(1.0f);
+  if (SIMPLE || m.coat_weight <= 0.0f) return splat(1.0f);
   const V3 dark = coat_darkening_factor(ld3(m.base_color), m.coat_ior, m.coat_darkening);
   return coat_passage(m, cos_v) * coat_passage(m, cos_l) * dark;
 }
@@ -421,10 +427,11 @@ __device__ __forceinline__ void eval_transmission(const CrtMaterial &m, V3 v_loc
   pdf = acc;
 }
 
+template <bool SIMPLE>
 __device__ __forceinline__ V3 eval_all(const CrtMaterial &m, V3 v_local, V3 l_local, bool entering) {  // :629-683
   if (v_local.z <= 0.0f) return splat(0.0f);
   if (l_local.z <= 0.0f) {
-    if (!transmission_is_continuous(m)) return splat(0.0f);
+    if (SIMPLE || !transmission_is_continuous(m)) return splat(0.0f);
     V3 val; float p;
     eval_transmission(m, v_local, l_local, entering, val, p);
     return val;
@@ -434,23 +441,24 @@ __device__ __forceinline__ V3 eval_all(const CrtMaterial &m, V3 v_local, V3 l_lo
   roughness_to_alpha(m.specular_roughness, m.specular_roughness_anisotropy, ax, ay);
   const float f_avg_diel = f0_from_ior(m.specular_ior);
   const V3 diffuse = eval_diffuse(m, v_local, l_local, f_avg_diel);
-  const V3 specular = eval_specular(m, v_local, l_local, h_local, ax, ay);
+  const V3 specular = eval_specular<SIMPLE>(m, v_local, l_local, h_local, ax, ay);
   V3 coat = splat(0.0f);
-  if (m.coat_weight > 0.0f) {
+  if (!SIMPLE && m.coat_weight > 0.0f) {
     float axc, ayc;
     roughness_to_alpha(m.coat_roughness, m.coat_roughness_anisotropy, axc, ayc);
     coat = eval_coat(m, v_local, l_local, h_local, axc, ayc);
   }
-  const V3 fuzz = m.fuzz_weight > 0.0f ? eval_fuzz(m, v_local, l_local, h_local) : splat(0.0f);
-  const V3 coat_atten = coat_attenuation(m, v_local.z, l_local.z);
+  const V3 fuzz = (!SIMPLE && m.fuzz_weight > 0.0f) ? eval_fuzz(m, v_local, l_local, h_local) : splat(0.0f);
+  const V3 coat_atten = coat_attenuation<SIMPLE>(m, v_local.z, l_local.z);
   const float base_atten = rclamp(1.0f - m.fuzz_weight, 0.0f, 1.0f);
   return fuzz + (coat + coat_atten * (diffuse + specular)) * base_atten;
 }
 
+template <bool SIMPLE>
 __device__ __forceinline__ float pdf_all(const CrtMaterial &m, const LobePmf &pmf, V3 v_local, V3 l_local, bool entering) {
   if (v_local.z <= 0.0f) return 0.0f;  // openpbr.rs:689-722
   if (l_local.z <= 0.0f) {
-    if (!transmission_is_continuous(m)) return 0.0f;
+    if (SIMPLE || !transmission_is_continuous(m)) return 0.0f;
     V3 val; float p;
     eval_transmission(m, v_local, l_local, entering, val, p);
     return pmf.p_transmission * p;
@@ -513,6 +521,7 @@ __device__ __forceinline__ V3 to_world(const Frame3 &f, V3 l) { return f.t * l.x
 
 // Material::scatter_importance (material.rs:40-45): OpenPBR::scatter_resolved (openpbr.rs:1026-1136);
 // Emissive never scatters (emissive.rs:30-38).
+template <bool SIMPLE>
 __device__ bool mat_scatter(const CrtMaterial &m, V3 ray_dir, const HitRec &rec, Sampler dom, Scatter &out,
                             const uint32_t *sobol_tab) {
   if (m.kind == CRT_MAT_EMISSIVE) return false;
@@ -526,12 +535,14 @@ __device__ bool mat_scatter(const CrtMaterial &m, V3 ray_dir, const HitRec &rec,
   const LobePmf pmf = lobe_pmf(m);
   const int lobe = lobe_pick(pmf, s[0]);
   if (lobe == LOBE_TRANSMISSION) {
-    if (transmission_is_continuous(m)) {
+    // SIMPLE keeps this arm's thin form: lobe_pick falls through to LOBE_TRANSMISSION whenever u lands past the
+    // rounded sum of the other four masses, even at transmission weight 0 (the reference does the same)
+    if (!SIMPLE && transmission_is_continuous(m)) {
       V3 l_local;
       if (!sample_transmission_rough(m, v_local, rec.front_face, s[3], s[1], s[2], l_local)) return false;
       const V3 l_world = to_world(frame, l_local);
-      const float pdf = rmax(pdf_all(m, pmf, v_local, l_local, rec.front_face), 1e-4f);
-      const V3 brdf = eval_all(m, v_local, l_local, rec.front_face);
+      const float pdf = rmax(pdf_all<SIMPLE>(m, pmf, v_local, l_local, rec.front_face), 1e-4f);
+      const V3 brdf = eval_all<SIMPLE>(m, v_local, l_local, rec.front_face);
       out.origin = rec.p + l_world * 1e-4f;
       out.dir = l_world;
       out.value = brdf * fabs_(l_local.z);
@@ -558,8 +569,8 @@ __device__ bool mat_scatter(const CrtMaterial &m, V3 ray_dir, const HitRec &rec,
     if (l.z <= 0.0f) return false;
     l_local = l;
   }
-  const float pdf = rmax(pdf_all(m, pmf, v_local, l_local, rec.front_face), 1e-4f);
-  const V3 brdf = eval_all(m, v_local, l_local, rec.front_face);
+  const float pdf = rmax(pdf_all<SIMPLE>(m, pmf, v_local, l_local, rec.front_face), 1e-4f);
+  const V3 brdf = eval_all<SIMPLE>(m, v_local, l_local, rec.front_face);
   const float n_dot_l = rmax(l_local.z, 0.0f);
   out.origin = rec.p;
   out.dir = to_world(frame, l_local);
@@ -570,6 +581,7 @@ __device__ bool mat_scatter(const CrtMaterial &m, V3 ray_dir, const HitRec &rec,
 }
 
 // Material::eval (material.rs:71-74): OpenPBR::eval_resolved (openpbr.rs:1138-1158); None for Emissive.
+template <bool SIMPLE>
 __device__ bool mat_eval(const CrtMaterial &m, V3 ray_dir, const HitRec &rec, V3 wi, V3 &value, float &pdf) {
   if (m.kind == CRT_MAT_EMISSIVE) return false;
   const Frame3 frame = frame_new(rec.normal);
@@ -577,16 +589,17 @@ __device__ bool mat_eval(const CrtMaterial &m, V3 ray_dir, const HitRec &rec, V3
   if (v_local.z <= 0.0f) return false;
   const V3 l_local = to_local(frame, normalize(wi));
   const LobePmf pmf = lobe_pmf(m);
-  pdf = rmax(pdf_all(m, pmf, v_local, l_local, rec.front_face), 1e-4f);
-  value = eval_all(m, v_local, l_local, rec.front_face) * fabs_(l_local.z);
+  pdf = rmax(pdf_all<SIMPLE>(m, pmf, v_local, l_local, rec.front_face), 1e-4f);
+  value = eval_all<SIMPLE>(m, v_local, l_local, rec.front_face) * fabs_(l_local.z);
   return true;
 }
 
 // Material::emitted_directional (material.rs:112-115; openpbr.rs:1211-1218).
+template <bool SIMPLE>
 __device__ __forceinline__ V3 mat_emitted_directional(const CrtMaterial &m, float cos_theta_o) {
   if (m.kind == CRT_MAT_EMISSIVE) return ld3(m.emission_color);
   const V3 uncoated = ld3(m.emission_color) * m.emission_luminance;
-  if (m.coat_weight <= 0.0f) return uncoated;
+  if (SIMPLE || m.coat_weight <= 0.0f) return uncoated;
   const V3 dark = coat_darkening_factor(ld3(m.base_color), m.coat_ior, m.coat_darkening);
   return uncoated * coat_passage(m, cos_theta_o) * dark;
 }
