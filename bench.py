@@ -251,6 +251,9 @@ def main():
             "mean_path_length": round(rays[3] / max(rays[2], 1), 3),
             "seconds": round(elapsed, 4),
             "spp_per_second": round(args.steps * spp_step / elapsed, 2),
+            # the second half of BASELINE's metric: wall clock to the configuration's target spp (configs[1]: 1024) at this rate
+            "target_spp": 1024,
+            "seconds_to_target_spp": round(elapsed * 1024.0 / (args.steps * spp_step), 4),
             "sharding": ("16x16 pixel tiles round-robin over ranks; one %s gather of tile buffers to rank 0" % ("RCCL" if args.backend == "nccl" else "gloo (rehearsal)")) if world > 1 else "none",
         },
         "roofline": roofline,
