@@ -492,3 +492,31 @@ def test_instance_hits_report_instance_geom_id_and_inner_prim_id():  # scene.rs:
     inst = b.attach_instance(inner.commit(), tr(0, 0, 5))
     h = b.commit().intersect(ray((-0.5, 0.5, 0), (0, 0, 1)))
     assert h.geom_id == inst and h.prim_id == 1
+
+
+# ---- scene.rs:602-655: has_motion ----
+def _unit_sphere_scene(api):
+    b = api.SceneBuilder()
+    b.attach_sphere((0.0, 0.0, 0.0), 1.0)
+    return b.commit()
+
+
+@pytest.mark.parametrize("which", ["oracle", "product"])
+def test_motion_flag_reports_a_static_scene_as_static(which, crt):  # scene.rs:602-619
+    api = ora if which == "oracle" else crt
+    assert not _unit_sphere_scene(api).has_motion()
+    b = api.SceneBuilder()
+    b.attach_instance(_unit_sphere_scene(api), api.affine(None, (3.0, 0.0, 0.0)))
+    assert not b.commit().has_motion()  # a static placement of static geometry is still static
+
+
+@pytest.mark.parametrize("which", ["oracle", "product"])
+def test_motion_flag_propagates_through_nesting(which, crt):  # scene.rs:621-655
+    api = ora if which == "oracle" else crt
+    mid = api.SceneBuilder()
+    mid.attach_instance(_unit_sphere_scene(api), api.affine(), api.affine(None, (4.0, 0.0, 0.0)))
+    mid = mid.commit()
+    assert mid.has_motion(), "the level that authored the motion"
+    root = api.SceneBuilder()
+    root.attach_instance(mid, api.affine(None, (0.0, 7.0, 0.0)))
+    assert root.commit().has_motion(), "a static placement of a moving scene is still moving"

@@ -682,3 +682,26 @@ def test_sampler_is_stratified_and_domains_decorrelate():
     assert L.ora_t_sampler_new(3, 5, 0, 0) != L.ora_t_sampler_new(4, 5, 0, 0) != L.ora_t_sampler_new(3, 5, 1, 0)
     r = [L.ora_t_rnd1(pat, i) for i in range(2048)]
     assert 0.45 < np.mean(r) < 0.55 and min(r) >= 0 and max(r) < 1
+
+
+# ---- tracer.rs:1615-1668: the sampling strategies' MIS weights ----
+_STRATEGIES = {"power": 0, "balance": 1, "light": 2, "bsdf": 3}  # ORA_STRATEGY_* (tracer.rs:63-75)
+
+
+def test_strategy_weights_partition_unity():  # tracer.rs:1620-1647
+    for s in _STRATEGIES.values():
+        for light_pdf, bounce_pdf in [(0.5, 0.5), (1e-4, 1e4), (1e4, 1e-4), (3.0, 0.2), (0.05, 40.0)]:
+            total = L.ora_light_weight(s, light_pdf, bounce_pdf) + L.ora_bounce_weight(s, bounce_pdf, light_pdf)
+            assert abs(total - 1.0) < 1e-3, (s, light_pdf, bounce_pdf, total)
+
+
+def test_single_strategy_modes_disable_the_other_side():  # tracer.rs:1649-1657
+    assert L.ora_light_weight(_STRATEGIES["light"], 1.0, 100.0) == 1.0
+    assert L.ora_bounce_weight(_STRATEGIES["light"], 100.0, 1.0) == 0.0
+    assert L.ora_light_weight(_STRATEGIES["bsdf"], 100.0, 1.0) == 0.0
+    assert L.ora_bounce_weight(_STRATEGIES["bsdf"], 1.0, 100.0) == 1.0
+
+
+def test_power_sharpens_balance():  # tracer.rs:1659-1667
+    a, b = 10.0, 1.0
+    assert L.ora_light_weight(_STRATEGIES["power"], a, b) > L.ora_light_weight(_STRATEGIES["balance"], a, b)
