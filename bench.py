@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--scene", default="cornellbox")
     ap.add_argument("--depth", type=int, default=None, help="override max depth (default: the scene's, 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=48, help="spp of the bounded CPU-baseline sample (per run)")
+    ap.add_argument("--cpu-spp", type=int, default=24, help="spp of the bounded CPU-baseline sample (per run; 3 runs of 24 spp are ~10 s on 16 cores)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = this box's share: min(affinity, 16 per GPU))")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1; gloo (CPU tensors, ranks may share a GPU) rehearses the N > 1 path on a 1-GPU box")
