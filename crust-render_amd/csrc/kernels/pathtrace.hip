@@ -409,8 +409,6 @@ __global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_extend(Params P, P
 }
 
 // ---- shade: one iteration of trace_path's loop body for every live path (tracer.rs:1118-1530) ----
-// MEDIA: some material of the scene has an interior medium; scenes without one run the leaner instance (the medium
-// code costs k_shade 80 spilled VGPRs at three waves per SIMD).
 // LIT: the light list is not empty. Unlit scenes (cornellbox, the bench scene: sky only) run an instance without the
 // light-sampling block, its second BSDF evaluation, the emitter MIS weights and the previous-vertex plane — code they
 // never execute, but whose registers and scalar constants the fused kernel otherwise carries through every bounce
@@ -573,7 +571,6 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
       const uint32_t hg = H.geom[i];
       const bool has_hit = hg != kInvalid;
       const uint32_t geom = hg & 0x7fffffffu;
-#ifndef CRT_NO_CLASS_STATS
       if (P.class_stats) {  // uniform; diagnostic only
         const uint32_t my = has_hit ? (uint32_t)P.mat_class[geom] : 0u;
 #pragma unroll
@@ -585,7 +582,6 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
           }
         }
       }
-#endif
       HitRec rec;
       rec.front_face = ((hg >> 31) & 1u) != 0;
       rec.t = 0.0f; rec.normal = splat(0.0f); rec.p = splat(0.0f);

@@ -314,6 +314,11 @@ int Scene::ensure_device() {
   }
   // Device form of a node's child words: leaf children carry the leaf tag (bit 31), empty lanes are CRT_INVALID_ID,
   // so the traversal derives everything from the word it has to load anyway and never touches `flags`.
+  // child words carry node and leaf indices below their tag bits (crt_internal.h)
+  if (f.nodes.size() >= (size_t(1) << 31) || f.leaves.size() >= (size_t(1) << 30)) {
+    set_error_text("scene image: %zu nodes / %zu leaves exceed the child word's index range", f.nodes.size(), f.leaves.size());
+    return CRT_ERR_UNSUPPORTED;
+  }
   bool direct = f.instances.size() >= 64 || f.packets.empty();
   if (const char *e = getenv("CRT_DIRECT_LEAVES")) direct = atoi(e) != 0;  // A/B runs
   if (!CRT_DIRECT_LEAVES) direct = false;  // an engine built without the direct form must never meet one
