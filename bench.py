@@ -19,11 +19,12 @@ fixed as N grows ("weak": N GPUs advance the frame N times as many spp per step)
 the only collective is ONE RCCL all_gather of the per-rank tile buffers after the last step (inside the timed
 region), plus the 64-bit ray counters.
 
-roofline: for the dominant kernel — k_path, which runs a whole batch (generate, every bounce's BVH4 traversal,
-shading and shadow stage) in one launch: algorithmic bytes (SURVEY §8d formulas; traversal counters from the stats
-build of the same stages on the same batch) over the HIP-event duration of its launches in the timed region, against
-the 8 TB/s HBM peak. `unfused_stage_ms_per_step` splits a step by stage (a second renderer with CRT_FUSED=0). cpu_baseline: the oracle (CPU restatement, "port") rendering a
-bounded sample of the same workload on this box's host cores.
+roofline: for the dominant kernel of the pipeline the renderer chose for the scene — k_extend, the BVH4 closest-hit
+traversal, for flat triangle scenes (one launch per stage and bounce, four workgroups per CU); k_path, which runs a whole
+batch (generate, every bounce's traversal, shading and shadow stage) in one launch, for instance-heavy scenes:
+algorithmic bytes (SURVEY §8d formulas; traversal counters from the stats build of the same stages on the same batch)
+over the HIP-event duration of its launches in the timed region, against the 8 TB/s HBM peak. cpu_baseline: the
+oracle (CPU restatement, "port") rendering a bounded sample of the same workload on this box's host cores.
 """
 import argparse
 import json
@@ -150,11 +151,15 @@ def main():
         return
 
     # ---- roofline of the dominant kernel, N=1 figures of rank 0 ----
-    # Default build: ONE kernel per step, k_path (generate + every bounce's traversal, shading and shadow stage of a
-    # workgroup-private queue segment). Algorithmic bytes per launch: the per-ray traversal
-    # formula summed over the closest-hit and the shadow rays of one batch (counters from the stats build of the
-    # same stages on the same batch) + 352 B per shaded vertex (path state 96 B each way + 160 B material record).
-    fused = os.environ.get("CRT_FUSED", "1") != "0"
+    # The renderer picks its pipeline per scene (crt.h, crt_renderer_pipeline). FUSED (instance-heavy, sphere-only):
+    # ONE kernel per step, k_path — generate + every bounce's traversal, shading and shadow stage of a workgroup-private
+    # queue segment. PER-STAGE (flat triangle scenes: cornellbox, the default workload): one launch per stage and
+    # bounce; the dominant kernel is k_extend, the BVH4 closest-hit traversal, at four workgroups per CU.
+    # Algorithmic bytes per launch: the per-ray traversal formula summed over the rays the
+    # kernel traces in one batch (counters from the stats build of the same stages on the same batch) [+ fused: the
+    # shadow rays' and 352 B per shaded vertex: path state 96 B each way + 160 B material record], over its launches.
+    pipe = r.pipeline()
+    fused = pipe["fused"]
     ext, sh = r.render_samples_stats(0, spp_step, stream)  # stats build, same batch shape; not timed
     trav_bytes = ext.algorithmic_bytes() + sh.algorithmic_bytes()
     shade_bytes = 352 * (st.vertices // max(args.steps, 1))
@@ -162,42 +167,54 @@ def main():
     k_ms, k_n = prof["extend"]["ms"], prof["extend"]["launches"]   # class 0: k_path when fused, k_extend otherwise
     per_launch = launch_bytes * args.steps / max(k_n, 1)
     achieved = per_launch / (k_ms / max(k_n, 1) * 1e-3) / 1e9 if k_ms > 0 else 0.0
-    # per-stage split from a second renderer that launches every stage separately (2 untimed steps)
-    stage = None
-    if fused:
-        os.environ["CRT_FUSED"] = "0"
-        try:
-            r2, _ = crt.load_usda(path, args.width, args.height, args.depth, rank=rank, world=world)
-            r2.render_samples(0, spp_step, stream)
-            torch.cuda.synchronize()
-            r2.profile(True)
-            for k in range(2):
-                r2.render_samples(k * spp_step, spp_step, stream)
-            torch.cuda.synchronize()
-            p2 = r2.profile_read()
+    # the other pipeline on the same workload, 2 untimed steps: per-stage split of a fused step / the fused kernel's time
+    stage = other = None
+    saved = {k: os.environ.get(k) for k in ("CRT_FUSED", "CRT_WIDE")}
+    try:
+        os.environ["CRT_FUSED"] = "0" if fused else "1"
+        r2, _ = crt.load_usda(path, args.width, args.height, args.depth, rank=rank, world=world)
+        r2.render_samples(0, spp_step, stream)
+        torch.cuda.synchronize()
+        r2.profile(True)
+        for k in range(2):
+            r2.render_samples(k * spp_step, spp_step, stream)
+        torch.cuda.synchronize()
+        p2 = r2.profile_read()
+        if fused:
             stage = {k: round(v["ms"] / 2, 3) for k, v in p2.items()}
             stage["extend_algorithmic_gb_s"] = round(ext.algorithmic_bytes() / (p2["extend"]["ms"] / 2 * 1e-3) / 1e9, 1)
-            del r2
-        finally:
-            os.environ["CRT_FUSED"] = "1"
+        else:
+            other = {"fused_k_path_ms_per_step": round(p2["extend"]["ms"] / 2, 3), "other": round(p2["other"]["ms"] / 2, 3)}
+        del r2
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     # Measured counters of the same kernel, from the committed PMC passes IF they are of this build and workload.
     workload_key = "%s %dx%d %dspp" % (args.scene, args.width, args.height, spp_step)
-    pmc, pmc_note = _pmc_for(workload_key, fused) if world == 1 else (None, "N > 1")
+    pmc, pmc_note = _pmc_for(workload_key, "k_path" if fused else "k_extend") if world == 1 else (None, "N > 1")
     avg_s = (k_ms / max(k_n, 1)) * 1e-3
-    traffic = hbm_frac = l2_hit = valu_issue = None
+    traffic = hbm_frac = l2_hit = valu_issue = wave = None
     if pmc and avg_s > 0:
         traffic = int(pmc["ea_dram_read_bytes_per_launch"] + pmc["ea_dram_write_bytes_per_launch"])
         hbm_frac = round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4)
         l2_hit = round(pmc["l2_hit_rate"], 4)
         # wave64 VALU instructions per second against the SIMDs' issue ceiling: CUs x 4 SIMD-32 x clock / 2 cycles
         valu_issue = round(pmc["valu_insts_per_launch"] / avg_s / (VALU_ISSUE_PEAK), 4)
+        # where a wave's time goes (SQ_ACTIVE_INST_ANY, SQ_WAIT_ANY, SQ_WAIT_INST_ANY over SQ_WAVE_CYCLES)
+        wave = {"issuing": pmc.get("inst_active_frac"), "waiting_on_memory": pmc.get("wait_any_frac"),
+                "waiting_for_instructions": pmc.get("wait_inst_frac")}
+    waves = 4 if pipe["wide"] else 3
     roofline = {
         "kernel": "k_path (one launch per batch: generate + BVH4 traversal + shading + shadow per queue segment)" if fused
-                  else "k_extend (BVH4 closest-hit traversal)",
+                  else "k_extend (BVH4 closest-hit traversal of one bounce's rays, %d workgroups per CU)" % waves,
+        "pipeline": "fused" if fused else ("per-stage, %d workgroups per CU in the traversal kernels" % waves),
         # `achieved` / `frac` are the task's definition: ALGORITHMIC bytes over kernel time against the HBM
         # peak. On this cache-resident scene most of those bytes never leave LDS / L1 / L2 — the physical picture is in
-        # the measured fields below: fabric-side traffic is a fraction of the peak and the SIMDs issue at about a third
-        # of their ceiling; the kernel is bound by dependent-load latency at 3 waves per SIMD, not by HBM.
+        # the measured fields below: fabric-side traffic is a fraction of the peak, a wave spends its time half issuing
+        # instructions and half waiting on memory; the kernel is bound by latency and issue at its occupancy, not by HBM.
         "bound": "hbm",
         "achieved": round(achieved, 2),
         "peak": HBM_PEAK_GBS,
@@ -208,16 +225,20 @@ def main():
         "hbm_measured_frac": hbm_frac,         # traffic / launch time / 8 TB/s
         "l2_hit": l2_hit,
         "valu_issue_frac": valu_issue,
-        "physical_bound": "dependent-load latency at 3 waves/SIMD (see hbm_measured_frac, valu_issue_frac)" if pmc else None,
+        "wave_time": wave,
+        "physical_bound": ("dependent-load latency and per-wave instruction issue at %d waves/SIMD (see wave_time, "
+                           "hbm_measured_frac, valu_issue_frac)" % waves) if pmc else None,
         "pmc_source": pmc_note,
         "kernel_source_hash": kernel_source_hash(),
         "launches": k_n,
+        "launches_per_step": round(k_n / max(args.steps, 1), 2),
         "avg_launch_ms": round(k_ms / max(k_n, 1), 5),
         "bytes_per_launch": int(per_launch),
         "traversal_bytes_per_ray": round(ext.algorithmic_bytes() / max(int(ext.rays), 1), 1),
         "shading_bytes_per_vertex": 352,
         "kernel_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
         "unfused_stage_ms_per_step": stage,
+        "other_pipeline": other,
     }
 
     cpu = None
@@ -311,13 +332,11 @@ def kernel_source_hash():
 PMC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc_bench.json")
 
 
-def _pmc_for(workload_key, fused):
-    """The committed rocprofv3 --pmc passes for this workload (profiles/r02_pmc_bench.json, written by
+def _pmc_for(workload_key, kernel):
+    """The committed rocprofv3 --pmc passes for this workload and kernel (profiles/r02_pmc_bench.json, written by
     profiles/summarize_pmc_bench.py) — but only if they were taken on THIS build: the file carries the kernel source
     hash of the build it profiled, and a profile of other sources says nothing about the kernel being timed now.
     Returns (entry or None, note)."""
-    if not fused:
-        return None, "PMC passes exist for the fused kernel only"
     if not os.path.exists(PMC_PROFILE):
         return None, "no PMC profile committed"
     try:
@@ -331,6 +350,8 @@ def _pmc_for(workload_key, fused):
     e = prof.get("workloads", {}).get(workload_key)
     if e is None:
         return None, "no PMC passes for workload %r" % workload_key
+    if not str(e.get("kernel", "")).startswith(kernel):
+        return None, "PMC passes for workload %r are of %s, the pipeline now runs %s" % (workload_key, e.get("kernel"), kernel)
     return e, "profiles/r02_pmc_bench.json (git %s)" % prof.get("git_commit", "?")
 
 

@@ -160,7 +160,7 @@ ABI_SYMBOLS = [
     "crt_renderer_pixel_count", "crt_renderer_pixel_indices", "crt_render_samples", "crt_film_resolve",
     "crt_film_read", "crt_film_clear", "crt_renderer_active_pixels", "crt_renderer_sample_counts", "crt_render_stats", "crt_renderer_profile", "crt_renderer_profile_read",
     "crt_render_samples_stats", "crt_version", "crt_last_error", "crt_device_info",
-    "crt_scene_primitive_extents", "crt_scene_traversal_error", "crt_thread_release", "crt_renderer_shade_class_stats",
+    "crt_scene_primitive_extents", "crt_scene_traversal_error", "crt_thread_release", "crt_renderer_shade_class_stats", "crt_renderer_pipeline",
 ]
 
 _lib = None
@@ -239,6 +239,8 @@ def lib():
         L.crt_renderer_active_pixels.argtypes = [vp]
         L.crt_renderer_sample_counts.argtypes = [vp, up]
         L.crt_renderer_profile.argtypes = [vp, C.c_int]
+        if hasattr(L, "crt_renderer_pipeline"):  # absent from older A/B variant libraries
+            L.crt_renderer_pipeline.argtypes = [vp, C.POINTER(C.c_uint32)]
         if hasattr(L, "crt_renderer_shade_class_stats"):  # absent from older A/B variant libraries
             L.crt_renderer_shade_class_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.crt_renderer_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
@@ -677,6 +679,12 @@ class Renderer:
         _check(lib().crt_renderer_shade_class_stats(self.h, -1 if enable is None else int(bool(enable)), w, l),
                "crt_renderer_shade_class_stats")
         return {n: (int(w[k]), (l[k] / (64.0 * w[k])) if w[k] else 0.0) for k, n in enumerate(self.SHADE_CLASSES)}
+
+    def pipeline(self):
+        """{'fused', 'wide', 'grid'}: the launch pipeline chosen for this scene (crt.h, crt_renderer_pipeline)."""
+        out = (C.c_uint32 * 3)()
+        _check(lib().crt_renderer_pipeline(self.h, out), "crt_renderer_pipeline")
+        return dict(fused=bool(out[0]), wide=bool(out[1]), grid=int(out[2]))
 
     def profile(self, enable=True):
         _check(lib().crt_renderer_profile(self.h, 1 if enable else 0), "crt_renderer_profile")

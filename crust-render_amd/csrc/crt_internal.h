@@ -121,19 +121,25 @@ struct DevPrim {  // 64 bytes
 };
 static_assert(sizeof(DevPrim) == 64, "");
 
-struct DevInstance {  // 192 bytes
+struct DevInstance {  // 64 bytes: what an instance entry reads (half a cache line; 40 000 placements stay L2-resident)
   float w2l[12];      // cached world-to-local at time 0 (prim.rs:266); its matrix3 transposed is the normal matrix (:267)
   uint32_t root;      // absolute node index of the instanced scene's root
-  uint32_t flags;     // bit 0: the instanced tree has Tri4 packets; bit 1: transform motion blur (prim.rs:276)
+  uint32_t flags;     // bit 0: the instanced tree has Tri4 packets; bit 1: transform motion blur (prim.rs:276);
+                      // bits 2..31: float offset of its DevInstanceMotion in `normals` (moving instances only)
   uint32_t geom_id;   // the instance's own geometry id and ray mask: a leaf's index list addresses an instance
   uint32_t mask;      //   record directly (kIndexInstance), so entering one never touches its DevPrim
+};
+static_assert(sizeof(DevInstance) == 64, "");
+// The two placements of a MOVING instance (prim.rs:285-331; flags bit 1), read only by a ray with a shutter time > 0:
+// 24 floats in the `normals` array at float offset flags >> 2. (Not an array of its own: every pointer of DevScene
+// is a pair of scalar registers live through the whole traversal, and the path kernels already spill those.)
+struct DevInstanceMotion {
   float l2w[12];
   float l2w_end[12];
-  uint32_t pad[8];
 };
-// Entries of `indices` (a leaf's scalar list): primitive index, or kIndexInstance | instance slot.
+// Entries of `indices` (a leaf's scalar list): primitive index, or kIndexInstance | instance slot. Instance slots
+// follow the order of the scalar lists, so the placements of one leaf, and of neighbouring leaves, share cache lines.
 constexpr uint32_t kIndexInstance = 0x80000000u;
-static_assert(sizeof(DevInstance) == 192, "");
 
 struct DevScene {
   const WideNode *nodes;
@@ -142,10 +148,11 @@ struct DevScene {
   const uint32_t *indices;
   const DevPrim *prims;
   const DevInstance *instances;
-  const float *normals;  // 9 floats per smooth triangle
+  const float *normals;  // 9 floats per smooth triangle; then 24 per moving instance
   uint32_t root;         // CRT_INVALID_ID when the scene is empty (bvh.rs:442-444)
   uint32_t has_packets;
-  uint32_t n_nodes;      // nodes are numbered breadth-first, top-level tree first (see Scene::ensure_device)
+  uint32_t n_nodes;      // numbered for the LDS window: top of the top-level tree, the instanced trees' roots, then
+                         // the rest breadth-first (see Scene::ensure_device)
   uint32_t pool_stack;   // LDS stack entries per ray the traversal engine uses for this scene (6 flat, 10 instanced)
   uint32_t n_packets;    // Tri4 packets, top-level tree first: the first ones are staged in LDS behind the node window
   uint32_t direct_leaves;  // leaves without packets and with 1-3 scalar entries are encoded in the child word (below)
@@ -153,17 +160,42 @@ struct DevScene {
 // Device child words of a node: inner child = node index; leaf child = kLeafTag | leaf index; empty lane =
 // CRT_INVALID_ID. With DevScene::direct_leaves a leaf that holds no Tri4 packet and one to three scalar entries
 // (spheres, instances: every leaf of an instanced city's top-level tree) is written as
-//   kLeafTag | kDirectLeafTag | count << 28 | idx_first
-// so the ray goes from the node straight to the scalar list: no 16-byte Leaf fetch and no packet step that finds
-// nothing. Chosen per scene at upload (instance-heavy or packet-free scenes), like the LDS split.
+//   kLeafTag | kDirectLeafTag | count << 28 | idx_first                    entries indices[idx_first ..)
+//   kLeafTag | kDirectLeafTag | count << 28 | kDirectInstTag | slot       entries = instances slot, slot + 1, ..
+// so the ray goes from the node straight to the scalar list: no 16-byte Leaf fetch, no packet step that finds
+// nothing and, when the entries are instances in consecutive slots, no index fetch either. Chosen per scene at
+// upload (instance-heavy or packet-free scenes), like the LDS split.
 constexpr uint32_t kDirectLeafTag = 0x40000000u;
+constexpr uint32_t kDirectInstTag = 0x08000000u;
+constexpr uint32_t kDirectIndexMask = 0x07ffffffu;
+// Nodes of the top of the tree the traversal kernels stage in LDS per workgroup (kernels/traverse_pool.hip.h): the
+// upload numbers the nodes for this window.
+#ifndef CRT_POOL_NODES_WIDE
+#define CRT_POOL_NODES_WIDE 8   // the four-workgroups-per-CU kernels (flat scenes)
+#endif
+#ifndef CRT_DIRECT_INST
+#define CRT_DIRECT_INST 1  // 0: the direct-instance form is neither written nor understood (A/B builds)
+#endif
+#ifndef CRT_POOL_NODES
+#define CRT_POOL_NODES 72
+#endif
+#ifndef CRT_POOL_NODES_DEEP
+#define CRT_POOL_NODES_DEEP 16  // with the deep stack: 16 still fit three workgroups per CU (+0.4 %); 24 do not (-33 %)
+#endif
 #ifndef CRT_DIRECT_LEAVES
 #define CRT_DIRECT_LEAVES 1  // 0: neither written by the upload nor understood by the engine (A/B builds)
 #endif
 
+// Which scenes the four-workgroups-per-CU traversal kernels (kernels/traverse_pool.hip.h, WIDE: four stack entries per
+// ray in LDS) are launched for: flat (not instance-heavy) triangle scenes whose trees are shallow enough for that
+// stack. Measured (profiles/README.md): the renderer's per-stage pipeline on them gains 4-9 % on cornellbox, veach_mis,
+// sun_sky (a few hundred nodes); 16 M incoherent rays against 43 200 triangles (3 600 nodes, 15 nodes per ray) lose
+// 7 %, an instanced city 6 %, sphere-only scenes are indifferent.
+inline bool wide_split(const DevScene &s) { return s.pool_stack < 10u && s.n_packets > 0 && s.n_nodes <= 2048u; }
+
 struct DeviceImage {
   void *blob = nullptr;
-  size_t bytes[7] = {0, 0, 0, 0, 0, 0, 0};  // nodes, leaves, packets, indices, prims, instances, normals
+  size_t bytes[7] = {0, 0, 0, 0, 0, 0, 0};  // nodes, leaves, packets, indices, prims, instances, normals (+ placements of moving instances)
   uint32_t *err = nullptr;  // this scene's traversal error word (the blob's last 256 bytes): crt_scene_traversal_error
   DevScene view{};
   ~DeviceImage();

@@ -287,7 +287,11 @@ constexpr int kClasses = 4;
 constexpr uint32_t kRing = 2 * kBlock;                 // entries per class ring: < kBlock pending + one classify batch
 constexpr int kRingDwords = kClasses * (int)kRing;
 constexpr int kClassLdsMax = 1024;                     // geom ids whose class byte is staged in LDS (1 KB)
-constexpr int kMatLdsMax = (kArenaDwords - kSobolLdsWords - kRingDwords - kClassLdsMax / 4) / (int)(sizeof(CrtMaterial) / 4);
+constexpr int mat_lds_max(int arena) { return (arena - kSobolLdsWords - kRingDwords - kClassLdsMax / 4) / (int)(sizeof(CrtMaterial) / 4); }
+// The per-stage shade kernel of simple-material scenes without lights at infinity also runs four workgroups per CU
+// (128 registers, a 40 KB arena: cornellbox +2 %); the other instances spill too much at 128 registers (sun_sky -16 %).
+constexpr int kArenaWide = 40 * 1024 / 4 - 256;
+static_assert(mat_lds_max(kArenaWide) >= 16 && mat_lds_max(kArenaDwords) >= 16, "the arena holds the Sobol tables, the rings and a material table");
 
 // Material class = which arms of the vertex code a hit on this material runs (openpbr.rs:1026-1136 dispatches one of
 // five lobes + thin film + dispersion per lane; rt_world.rs:219-231 binds the material per geom_id). Waves whose
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(Params P, PathSoA S, Counte
 }
 
 // ---- extend: World::intersect (rt_world.rs:207-232) for every live path ----
-template <bool STATS>
+template <bool STATS, bool WIDE>
 __device__ __forceinline__ void extend_segment(const Params &P, const PathSoA &S, const HitSoA &H, Counters *C, int cur,
                                                int first, CrtTravStats *tstats, uint32_t *engine_lds) {
   __shared__ uint32_t pre[kBins + 1];
@@ -397,15 +401,16 @@ __device__ __forceinline__ void extend_segment(const Params &P, const PathSoA &S
     }
     done++;
   };
-  run_traversal<false, STATS>(P.scene, engine_lds, 0.001f, err, st, fetch, emit);
+  run_traversal<false, STATS, WIDE>(P.scene, engine_lds, 0.001f, err, st, fetch, emit);
   if (err) atomicOr(&C->err, err);
   if (STATS) flush_stats(st, tstats, done);
 }
-template <bool STATS>
-__global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_extend(Params P, PathSoA S, HitSoA H, Counters *C, int cur, int first,
-                                                   CrtTravStats *tstats) {
-  __shared__ __attribute__((aligned(16))) uint32_t engine_lds[kEngineLdsDwords];
-  extend_segment<STATS>(P, S, H, C, cur, first, tstats, engine_lds);
+// WIDE: the four-workgroups-per-CU split of the engine (traverse_pool.hip.h), the per-stage pipeline of flat scenes.
+template <bool STATS, bool WIDE>
+__global__ __launch_bounds__(kBlock, WIDE ? 4 : CRT_EXTEND_WAVES) void k_extend(Params P, PathSoA S, HitSoA H, Counters *C, int cur,
+                                                                     int first, CrtTravStats *tstats) {
+  __shared__ __attribute__((aligned(16))) uint32_t engine_lds[WIDE ? kEngineLdsWide : kEngineLdsDwords];
+  extend_segment<STATS, WIDE>(P, S, H, C, cur, first, tstats, engine_lds);
 }
 
 // ---- shade: one iteration of trace_path's loop body for every live path (tracer.rs:1118-1530) ----
@@ -415,10 +420,10 @@ __global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_extend(Params P, P
 // (cornellbox +1.3 %, MedCity +2 %, profiles/README.md). With lights present the strategy is checked at run time.
 // MATS: what the scene's material table holds — 0 simple (no coat, fuzz, thin film, transmission, subsurface anywhere:
 // the OpenPBR code is instantiated without those arms, shade.hip.h), 1 general, 2 general with interior media.
-template <int MATS, bool INF, bool LIT>
+template <int MATS, bool INF, bool LIT, int ARENA>
 __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S, const PathSoA &N, const HitSoA &H,
                                               const ShadowSoA &Q, Counters *C, int cur, float4 *staging,
-                                              uint32_t *sobol_tab /* kArenaDwords: Sobol tables, then the material table */) {
+                                              uint32_t *sobol_tab /* ARENA dwords: Sobol tables, then the material table */) {
   constexpr bool MEDIA = MATS == 2, SIMPLE = MATS == 0;
   __shared__ uint32_t lds_ctr[10];  // [1] shadow requests, [2..8] statistics
   __shared__ uint32_t out_n[kBins];  // survivors per direction bin
@@ -437,7 +442,7 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
   // round trips to L2 per vertex. A table that fits the rest of the arena is staged in LDS once per call instead
   // (generic pointer: the reads become FLAT loads served by LDS); larger tables stay in global memory.
   const CrtMaterial *mats = P.materials;
-  if (P.n_materials <= (uint32_t)kMatLdsMax) {
+  if (P.n_materials <= (uint32_t)mat_lds_max(ARENA)) {
     uint32_t *dst = sobol_tab + kSobolLdsWords;
     const uint32_t *src = reinterpret_cast<const uint32_t *>(P.materials);
     const uint32_t words = P.n_materials * (uint32_t)(sizeof(CrtMaterial) / 4);
@@ -457,7 +462,7 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
   // SHADE step takes its 256 from ONE ring — the fullest — so all four waves of the step run one class's arms. The
   // class comes from a byte table by geom_id (LDS when it fits). Per-path arithmetic does not depend on which lanes
   // share a wave, and every output slot is private to its path, so images and counters do not change.
-  uint32_t *ring = sobol_tab + kArenaDwords - kRingDwords;        // [kClasses][kRing]
+  uint32_t *ring = sobol_tab + ARENA - kRingDwords;               // [kClasses][kRing]
   uint8_t *cls_lds = reinterpret_cast<uint8_t *>(ring) - kClassLdsMax;
   __shared__ uint32_t ring_tail[kClasses];  // entries ever appended, per class (heads are tracked in registers: uniform)
   const bool part = P.partition != 0;
@@ -783,15 +788,16 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
   if (threadIdx.x >= 1 && threadIdx.x <= 7 && lds_ctr[threadIdx.x + 1])
     atomicAdd(&C->stats[threadIdx.x], (unsigned long long)lds_ctr[threadIdx.x + 1]);
 }
-template <int MATS, bool INF>
-__global__ __launch_bounds__(kBlock, CRT_SHADE_WAVES) void k_shade(Params P, PathSoA S, PathSoA N, HitSoA H, ShadowSoA Q, Counters *C,
-                                                  int cur, float4 *staging) {
-  __shared__ uint32_t sobol_tab[kArenaDwords];
-  shade_segment<MATS, INF, true>(P, S, N, H, Q, C, cur, staging, sobol_tab);
+template <int MATS, bool INF, bool WIDE>
+__global__ __launch_bounds__(kBlock, WIDE ? 4 : CRT_SHADE_WAVES) void k_shade(Params P, PathSoA S, PathSoA N, HitSoA H, ShadowSoA Q,
+                                                                   Counters *C, int cur, float4 *staging) {
+  constexpr int ARENA = WIDE ? kArenaWide : kArenaDwords;
+  __shared__ uint32_t sobol_tab[ARENA];
+  shade_segment<MATS, INF, true, ARENA>(P, S, N, H, Q, C, cur, staging, sobol_tab);
 }
 
 // ---- shadow: World::occluded (rt_world.rs:235-237) for the queue; unoccluded requests pay out ----
-template <bool STATS>
+template <bool STATS, bool WIDE>
 __device__ __forceinline__ void shadow_segment(const Params &P, const PathSoA &N, const ShadowSoA &Q, Counters *C,
                                                float4 *staging, CrtTravStats *tstats, uint32_t *engine_lds) {
   const uint32_t n = ((const volatile uint32_t *)C->shadow)[blockIdx.x];
@@ -826,15 +832,15 @@ __device__ __forceinline__ void shadow_segment(const Params &P, const PathSoA &N
       N.c[tg] = v;
     }
   };
-  run_traversal<true, STATS>(P.scene, engine_lds, 0.001f, err, st, fetch, emit);
+  run_traversal<true, STATS, WIDE>(P.scene, engine_lds, 0.001f, err, st, fetch, emit);
   if (err) atomicOr(&C->err, err);
   if (STATS) flush_stats(st, tstats, done);
 }
-template <bool STATS>
-__global__ __launch_bounds__(kBlock, CRT_SHADOW_WAVES) void k_shadow(Params P, PathSoA N, ShadowSoA Q, Counters *C, float4 *staging,
-                                                   CrtTravStats *tstats) {
-  __shared__ __attribute__((aligned(16))) uint32_t engine_lds[kEngineLdsDwords];
-  shadow_segment<STATS>(P, N, Q, C, staging, tstats, engine_lds);
+template <bool STATS, bool WIDE>
+__global__ __launch_bounds__(kBlock, WIDE ? 4 : CRT_SHADOW_WAVES) void k_shadow(Params P, PathSoA N, ShadowSoA Q, Counters *C,
+                                                                     float4 *staging, CrtTravStats *tstats) {
+  __shared__ __attribute__((aligned(16))) uint32_t engine_lds[WIDE ? kEngineLdsWide : kEngineLdsDwords];
+  shadow_segment<STATS, WIDE>(P, N, Q, C, staging, tstats, engine_lds);
 }
 
 // ---- the whole path loop of one wavefront batch in ONE launch. Queue segments are private to their workgroup at
@@ -853,12 +859,12 @@ __global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_path(Params P, Pat
   for (uint32_t it = 0; it <= P.max_depth; it++) {
     const PathSoA &S = cur ? S1 : S0;
     const PathSoA &N = cur ? S0 : S1;
-    extend_segment<false>(P, S, H, C, cur, it == 0 ? 1 : 0, nullptr, arena);
+    extend_segment<false, false>(P, S, H, C, cur, it == 0 ? 1 : 0, nullptr, arena);
     __syncthreads();  // hit records of this segment are complete; the arena changes hands
-    shade_segment<MATS, INF, LIT>(P, S, N, H, Q, C, cur, staging, arena);
+    shade_segment<MATS, INF, LIT, kArenaDwords>(P, S, N, H, Q, C, cur, staging, arena);
     __syncthreads();
     if (LIT) {
-      shadow_segment<false>(P, N, Q, C, staging, nullptr, arena);
+      shadow_segment<false, false>(P, N, Q, C, staging, nullptr, arena);
       __syncthreads();
     }
     cur = 1 - cur;
@@ -978,7 +984,10 @@ struct Renderer {
   uint32_t *d_state = nullptr, *d_active = nullptr, *d_count = nullptr;
   uint32_t n_act = 0, min_spp = 2;
   float variance_threshold = 0.0f;
-  bool fused = true;  // CRT_FUSED=0: one launch per stage and bounce (per-stage timing, A/B)
+  // Two pipelines, chosen per scene at creation (crt_renderer_new): FUSED — the whole path loop of a batch in one launch
+  // (k_path, three workgroups per CU) for instance-heavy scenes — and PER-STAGE with the WIDE traversal kernels (four
+  // workgroups per CU) for flat ones. CRT_FUSED / CRT_WIDE override (A/B, per-stage timing).
+  bool fused = true, wide = false;
   CrtLight *d_lights = nullptr;
   uint32_t *d_pixels = nullptr;
   int grid = 2048;
@@ -1120,17 +1129,25 @@ struct Renderer {
     timed(3, st, [&] { hipLaunchKernelGGL(k_generate, dim3(grid), dim3(kBlock), 0, st, p, S[0], C, sample_begin, n_samples); });
     int cur = 0;
     for (uint32_t it = 0; it <= P.max_depth; it++) {
-      if (d_tstats) timed(0, st, [&] { hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kBlock), 0, st, p, S[cur], H, C, cur, it == 0 ? 1 : 0, d_tstats); });
-      else timed(0, st, [&] { hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kBlock), 0, st, p, S[cur], H, C, cur, it == 0 ? 1 : 0, d_tstats); });
-#define CRT_SHADE(M, I) \
-  timed(1, st, [&] { hipLaunchKernelGGL((k_shade<M, I>), dim3(grid), dim3(kBlock), 0, st, p, S[cur], S[1 - cur], H, Q, C, cur, staging); })
-      if (mats_kind == 2) { if (P.has_inf_lights) CRT_SHADE(2, true); else CRT_SHADE(2, false); }
-      else if (mats_kind == 1) { if (P.has_inf_lights) CRT_SHADE(1, true); else CRT_SHADE(1, false); }
-      else { if (P.has_inf_lights) CRT_SHADE(0, true); else CRT_SHADE(0, false); }
+#define CRT_EXTEND(ST, W) \
+  timed(0, st, [&] { hipLaunchKernelGGL((k_extend<ST, W>), dim3(grid), dim3(kBlock), 0, st, p, S[cur], H, C, cur, it == 0 ? 1 : 0, d_tstats); })
+      if (d_tstats) { if (wide) CRT_EXTEND(true, true); else CRT_EXTEND(true, false); }
+      else { if (wide) CRT_EXTEND(false, true); else CRT_EXTEND(false, false); }
+#undef CRT_EXTEND
+#define CRT_SHADE(M, I, W) \
+  timed(1, st, [&] { hipLaunchKernelGGL((k_shade<M, I, W>), dim3(grid), dim3(kBlock), 0, st, p, S[cur], S[1 - cur], H, Q, C, cur, staging); })
+      if (mats_kind == 2) { if (P.has_inf_lights) CRT_SHADE(2, true, false); else CRT_SHADE(2, false, false); }
+      else if (mats_kind == 1) { if (P.has_inf_lights) CRT_SHADE(1, true, false); else CRT_SHADE(1, false, false); }
+      else if (P.has_inf_lights) CRT_SHADE(0, true, false);
+      else if (wide) CRT_SHADE(0, false, true);
+      else CRT_SHADE(0, false, false);
 #undef CRT_SHADE
       if (P.n_lights > 0 && P.strategy != CRT_STRATEGY_BSDF) {
-        if (d_tstats) timed(2, st, [&] { hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(kBlock), 0, st, p, S[1 - cur], Q, C, staging, d_tstats + 1); });
-        else timed(2, st, [&] { hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(kBlock), 0, st, p, S[1 - cur], Q, C, staging, d_tstats); });
+#define CRT_SHADOW(ST, W) \
+  timed(2, st, [&] { hipLaunchKernelGGL((k_shadow<ST, W>), dim3(grid), dim3(kBlock), 0, st, p, S[1 - cur], Q, C, staging, d_tstats ? d_tstats + 1 : nullptr); })
+        if (d_tstats) { if (wide) CRT_SHADOW(true, true); else CRT_SHADOW(true, false); }
+        else { if (wide) CRT_SHADOW(false, true); else CRT_SHADOW(false, false); }
+#undef CRT_SHADOW
       }
       cur = 1 - cur;
     }
@@ -1266,13 +1283,21 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
   hipDeviceProp_t prop;
   int dev = 0;
   (void)hipGetDevice(&dev);
-  // Workgroups per CU = queue segments per CU. 3 is what stays resident (LDS of the traversal engine), so every
-  // segment is as long as it can be and a wave's ray pool drains only once per launch.
-  int mult = 3;
-  if (const char *e = getenv("CRT_GRID_MULT")) mult = atoi(e) > 0 ? atoi(e) : 3;  // tuning knob
+  // Pipeline by scene (see Renderer::fused; crt_internal.h, wide_split): small flat triangle scenes gain 4-9 % from
+  // the fourth wave per SIMD of the per-stage kernels; an instanced city loses 6 % to their four-entry LDS stack, and a
+  // scene of analytic spheres only (openpbr_showcase: next to no traversal, all shading) 1 % to the hit records' round
+  // trip (profiles/README.md).
+  r.wide = wide_split(P.scene);
+  if (const char *e = getenv("CRT_WIDE")) r.wide = atoi(e) != 0;
+  r.fused = !r.wide;
+  if (const char *e = getenv("CRT_FUSED")) r.fused = atoi(e) != 0;
+  // Workgroups per CU = queue segments per CU. Fused: 3, what stays resident (LDS of the traversal engine), so every
+  // segment is as long as it can be and a wave's ray pool drains only once per launch. Per-stage wide: 8, two rounds of
+  // the four resident workgroups (measured: 4 / 8 / 12 / 16 -> cornellbox 7480 / 7790 / 7500 / 7490 Mray/s).
+  int mult = r.fused ? 3 : (r.wide ? 8 : 3);
+  if (const char *e = getenv("CRT_GRID_MULT")) mult = atoi(e) > 0 ? atoi(e) : mult;  // tuning knob
   if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) r.grid = prop.multiProcessorCount * mult;
   if (r.grid > kMaxGrid) r.grid = kMaxGrid;
-  if (const char *e = getenv("CRT_FUSED")) r.fused = atoi(e) != 0;
   return R;
 }
 void crt_renderer_free(CrtRenderer *r) { delete r; }
@@ -1369,6 +1394,13 @@ int crt_renderer_shade_class_stats(CrtRenderer *r, int enable, uint64_t out_wave
     for (int c = 0; c < 4; c++) { out_waves[c] = h[c]; out_lanes[c] = h[4 + c]; }
   }
   if (enable >= 0) R.P.class_stats = enable ? 1u : 0u;
+  return CRT_OK;
+}
+int crt_renderer_pipeline(const CrtRenderer *r, uint32_t out[3]) {
+  if (!r || !out) return CRT_ERR_BAD_ARG;
+  out[0] = r->r.fused ? 1u : 0u;
+  out[1] = (!r->r.fused && r->r.wide) ? 1u : 0u;
+  out[2] = (uint32_t)r->r.grid;
   return CRT_OK;
 }
 int crt_renderer_profile(CrtRenderer *r, int enable) {

@@ -1,5 +1,7 @@
 // Batched Scene::intersect / Scene::occluded kernels (scene.rs:354-372) over the device image.
 // Compile with -ffp-contract=off (see traverse.hip.h).
+#include <cstdlib>
+
 #include "traverse_pool.hip.h"
 
 static_assert(crt::dev::kMaxLevels == (int)crt::kMaxInstanceLevels, "commit's nesting limit is the kernels' frame count");
@@ -30,11 +32,12 @@ __device__ __forceinline__ bool lds_take(bool want, uint32_t *next, uint32_t lim
   return want && idx < limit;
 }
 
-template <bool STATS>
-__global__ __launch_bounds__(kBlock) void intersect_n_kernel(DevScene S, const CrtRay *__restrict__ rays, size_t n,
+// WIDE: the four-workgroups-per-CU split of the engine (traverse_pool.hip.h), launched for flat scenes.
+template <bool STATS, bool WIDE>
+__global__ __launch_bounds__(kBlock, WIDE ? 4 : 3) void intersect_n_kernel(DevScene S, const CrtRay *__restrict__ rays, size_t n,
                                                             float t_min, float t_max, CrtRayHit *__restrict__ hits,
                                                             uint32_t *__restrict__ err_out, CrtTravStats *stats) {
-  __shared__ __attribute__((aligned(16))) uint32_t engine_lds[kEngineLdsDwords];
+  __shared__ __attribute__((aligned(16))) uint32_t engine_lds[WIDE ? kEngineLdsWide : kEngineLdsDwords];
   __shared__ uint32_t next;
   const Chunk ck = my_chunk(n);
   if (ck.count == 0) return;
@@ -68,16 +71,16 @@ __global__ __launch_bounds__(kBlock) void intersect_n_kernel(DevScene S, const C
     hits[i] = out;
     done++;
   };
-  run_traversal<false, STATS>(S, engine_lds, t_min, err, st, fetch, emit);
+  run_traversal<false, STATS, WIDE>(S, engine_lds, t_min, err, st, fetch, emit);
   if (err) atomicOr(err_out, err);
   if (STATS) flush_stats(st, stats, done);
 }
 
-template <bool STATS>
-__global__ __launch_bounds__(kBlock) void occluded_n_kernel(DevScene S, const CrtRay *__restrict__ rays, size_t n,
+template <bool STATS, bool WIDE>
+__global__ __launch_bounds__(kBlock, WIDE ? 4 : 3) void occluded_n_kernel(DevScene S, const CrtRay *__restrict__ rays, size_t n,
                                                            float t_min, float t_max, uint32_t *__restrict__ out,
                                                            uint32_t *__restrict__ err_out, CrtTravStats *stats) {
-  __shared__ __attribute__((aligned(16))) uint32_t engine_lds[kEngineLdsDwords];
+  __shared__ __attribute__((aligned(16))) uint32_t engine_lds[WIDE ? kEngineLdsWide : kEngineLdsDwords];
   __shared__ uint32_t next;
   const Chunk ck = my_chunk(n);
   if (ck.count == 0) return;
@@ -97,12 +100,18 @@ __global__ __launch_bounds__(kBlock) void occluded_n_kernel(DevScene S, const Cr
     out[ck.first + k] = occ ? 1u : 0u;
     done++;
   };
-  run_traversal<true, STATS>(S, engine_lds, t_min, err, st, fetch, emit);
+  run_traversal<true, STATS, WIDE>(S, engine_lds, t_min, err, st, fetch, emit);
   if (err) atomicOr(err_out, err);
   if (STATS) flush_stats(st, stats, done);
 }
 
-int grid_for(size_t n) {
+// Small flat triangle scenes run the WIDE kernels (four workgroups resident per CU), the others the scene's own split
+// on three (crt_internal.h, wide_split).
+bool wide_scene(const DevScene &s) {
+  if (const char *e = getenv("CRT_WIDE")) return atoi(e) != 0;  // A/B runs, tests
+  return wide_split(s);
+}
+int grid_for(size_t n, bool wide) {
   static int cus = [] {
     hipDeviceProp_t prop;
     int dev = 0;
@@ -111,7 +120,7 @@ int grid_for(size_t n) {
     return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }();
   size_t need = (n + kBlock - 1) / kBlock;
-  size_t cap = (size_t)cus * 3;  // what stays resident per CU (LDS of the traversal engine): one chunk per workgroup
+  size_t cap = (size_t)cus * (wide ? 4 : 3);  // what stays resident per CU (LDS of the traversal engine): one chunk per workgroup
   return (int)(need < cap ? (need ? need : 1) : cap);
 }
 
@@ -121,13 +130,14 @@ int launch_intersect_n(const DevScene &s, const CrtRay *d_rays, size_t n, float 
                        void *stream, CrtTravStats *d_stats, uint32_t *e) {
   if (n == 0) return CRT_OK;
   if (!e) return CRT_ERR_BAD_ARG;
-  const int grid = grid_for(n);
-  if (d_stats)
-    hipLaunchKernelGGL(intersect_n_kernel<true>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, s, d_rays, n, t_min,
-                       t_max, d_hits, e, d_stats);
-  else
-    hipLaunchKernelGGL(intersect_n_kernel<false>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, s, d_rays, n, t_min,
-                       t_max, d_hits, e, d_stats);
+  const bool wide = wide_scene(s);
+  const int grid = grid_for(n, wide);
+#define CRT_LAUNCH(ST, W)                                                                                             \
+  hipLaunchKernelGGL((intersect_n_kernel<ST, W>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, s, d_rays, n, t_min, \
+                     t_max, d_hits, e, d_stats)
+  if (d_stats) { if (wide) CRT_LAUNCH(true, true); else CRT_LAUNCH(true, false); }
+  else { if (wide) CRT_LAUNCH(false, true); else CRT_LAUNCH(false, false); }
+#undef CRT_LAUNCH
   return CRT_HIP_OK(hipGetLastError()) ? CRT_OK : CRT_ERR_NO_DEVICE;
 }
 
@@ -135,13 +145,14 @@ int launch_occluded_n(const DevScene &s, const CrtRay *d_rays, size_t n, float t
                       void *stream, CrtTravStats *d_stats, uint32_t *e) {
   if (n == 0) return CRT_OK;
   if (!e) return CRT_ERR_BAD_ARG;
-  const int grid = grid_for(n);
-  if (d_stats)
-    hipLaunchKernelGGL(occluded_n_kernel<true>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, s, d_rays, n, t_min,
-                       t_max, d_out, e, d_stats);
-  else
-    hipLaunchKernelGGL(occluded_n_kernel<false>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, s, d_rays, n, t_min,
-                       t_max, d_out, e, d_stats);
+  const bool wide = wide_scene(s);
+  const int grid = grid_for(n, wide);
+#define CRT_LAUNCH(ST, W)                                                                                            \
+  hipLaunchKernelGGL((occluded_n_kernel<ST, W>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, s, d_rays, n, t_min, \
+                     t_max, d_out, e, d_stats)
+  if (d_stats) { if (wide) CRT_LAUNCH(true, true); else CRT_LAUNCH(true, false); }
+  else { if (wide) CRT_LAUNCH(false, true); else CRT_LAUNCH(false, false); }
+#undef CRT_LAUNCH
   return CRT_HIP_OK(hipGetLastError()) ? CRT_OK : CRT_ERR_NO_DEVICE;
 }
 

@@ -187,7 +187,7 @@ __device__ __forceinline__ void tri_normal(const DevScene &S, uint32_t prim_abs,
 }
 
 // glam Affine3A at a shutter time (prim.rs:285-331): lerp of the two placements, inverted.
-__device__ __forceinline__ void motion_w2l(const DevInstance &in, float time, float w2l[12]) {
+__device__ __forceinline__ void motion_w2l(const DevInstanceMotion &in, float time, float w2l[12]) {
   float m[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) m[i] = in.l2w[i] * (1.0f - time) + in.l2w_end[i] * time;
@@ -210,11 +210,12 @@ __device__ __forceinline__ void motion_w2l(const DevInstance &in, float time, fl
 
 // InstancePrim::hit's normal step (prim.rs:327, :358-364): n <- normalize(w2l.matrix3^T * n), w2l the cached one or
 // the shutter-time one (prim.rs:285-331).
-__device__ __forceinline__ void instance_normal(const DevInstance &in, float time, float &nx, float &ny, float &nz) {
+__device__ __forceinline__ void instance_normal(const DevScene &S, uint32_t inst, float time, float &nx, float &ny, float &nz) {
+  const DevInstance &in = S.instances[inst];
   float nm[9];
   if ((in.flags & 2u) && time > 0.0f) {
     float w2l[12];
-    motion_w2l(in, time, w2l);
+    motion_w2l(*reinterpret_cast<const DevInstanceMotion *>(S.normals + (in.flags >> 2)), time, w2l);
     nm[0] = w2l[0]; nm[1] = w2l[3]; nm[2] = w2l[6];
     nm[3] = w2l[1]; nm[4] = w2l[4]; nm[5] = w2l[7];
     nm[6] = w2l[2]; nm[7] = w2l[5]; nm[8] = w2l[8];

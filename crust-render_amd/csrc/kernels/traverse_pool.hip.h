@@ -30,6 +30,9 @@ namespace dev {
 #ifndef CRT_DEFER_NORMAL
 #define CRT_DEFER_NORMAL 1  // a level-1 instanced hit's normal is taken to world space at emit, not at every exit
 #endif
+#ifndef CRT_LDS_ROOT
+#define CRT_LDS_ROOT 1  // the root test at entry reads a root staged in the LDS window from LDS
+#endif
 #ifndef CRT_FETCH_MIN
 #define CRT_FETCH_MIN 40
 #endif
@@ -42,11 +45,14 @@ namespace dev {
 // the instance's and run +6 % with ten entries and next to no window (profiles/README.md). The host picks the split
 // per scene (DevScene::pool_stack); both fit the same arena.
 constexpr int kPoolStack = CRT_POOL_STACK;       // flat scenes
-constexpr int kPoolStackDeep = 10;               // instance-heavy scenes
+#ifndef CRT_POOL_STACK_DEEP
+#define CRT_POOL_STACK_DEEP 10
+#endif
+constexpr int kPoolStackDeep = CRT_POOL_STACK_DEEP;  // instance-heavy scenes
 // Private part of the stack. sp lives in 8 bits of the ctl word, so LDS part + private part must not exceed 255 with
 // EITHER split: a push at the limit then takes the err path (CRT_ERR_STACK) instead of wrapping into `base`.
-constexpr int kPoolSpill = 255 - (CRT_POOL_STACK > 10 ? CRT_POOL_STACK : 10);
-static_assert(CRT_POOL_STACK + kPoolSpill <= 255 && 10 + kPoolSpill <= 255, "sp must fit the ctl word's 8 bits");
+constexpr int kPoolSpill = 255 - (kPoolStack > kPoolStackDeep ? kPoolStack : kPoolStackDeep);
+static_assert(kPoolStack + kPoolSpill <= 255 && kPoolStackDeep + kPoolSpill <= 255, "sp must fit the ctl word's 8 bits");
 constexpr int kFetchMin = CRT_FETCH_MIN;     // fetch new rays once this many lanes have a free slot
 #ifndef CRT_EMIT_BIAS
 #define CRT_EMIT_BIAS 16
@@ -100,7 +106,7 @@ __device__ __forceinline__ int wave_count(bool p) {
   return n;
 }
 
-template <bool ANY, bool STATS, int ROWS, bool DIRECT, class Fetch, class Emit>
+template <bool ANY, bool STATS, int ROWS, bool DIRECT, bool LEAN, class Fetch, class Emit>
 __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's pool_lds_dwords<ROWS>() */, float t_min,
                               const uint32_t *lds_nodes /* staged top of the tree */, uint32_t n_lds,
                               uint32_t n_lds_pk /* packets staged behind the n_lds nodes */, uint32_t pstack,
@@ -157,7 +163,9 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
   constexpr bool direct_leaves = DIRECT;  // the caller instantiates the engine per DevScene::direct_leaves
   auto leaf_word = [&](uint32_t e, uint32_t level, uint32_t &cur, uint32_t &cursor, uint32_t &rem) -> uint32_t {
     if (direct_leaves && (e & kDirectLeafTag)) {
-      cursor = e & 0x0fffffffu;
+      // entries: indices[cursor ..), or — kDirectInstTag — the instance slots themselves, carried in the cursor in the
+      // list's own form (kIndexInstance | slot) so the scalar step needs no index fetch
+      cursor = (CRT_DIRECT_INST && (e & kDirectInstTag)) ? (kIndexInstance | (e & kDirectIndexMask)) : (e & kDirectIndexMask);
       rem = (e >> 28) & 3u;
       if (STATS) { st.leaves[level > 0 ? 1 : 0]++; st.prims[level > 0 ? 1 : 0] += rem; }
       return PH_SCALAR;
@@ -425,27 +433,83 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
       bool act = mine;
       for (;;) {
         if (act) {
-          const Leaf lf = S.leaves[cur];
+          // The leaf record whole, in one 16-byte load: read field by field the compiler fetches pkt_first in a second,
+          // dependent round trip (it is used only when the leaf has a packet left).
+          Leaf lf;
+          {
+            uint4 lw = *reinterpret_cast<const uint4 *>(&S.leaves[cur]);
+            asm volatile("" : "+v"(lw.x), "+v"(lw.y), "+v"(lw.z), "+v"(lw.w));
+            lf.pkt_first = lw.x; lf.pkt_count = lw.y; lf.idx_first = lw.z; lf.idx_count = lw.w;
+          }
           const int sl = level > 0 ? 1 : 0;
           if (STATS && k == 0) { st.leaves[sl]++; st.packets[sl] += lf.pkt_count; st.prims[sl] += lf.idx_count; }
           if (k < lf.pkt_count) {
             const uint32_t pki = lf.pkt_first + k;
-            // A packet of the staged window is read from LDS (ds_read_b128), the rest from L2. The address-space
-            // cast is kept out of the optimiser's sight only as far as needed: one select of the base pointer.
-            const Tri4 *pk = &S.packets[pki];
+            // A packet of the staged window is read from LDS (ds_read_b128), the rest from L2; two arms, as for the
+            // nodes: merged they become FLAT loads through a generic pointer.
             const bool pk_lds = pki < n_lds_pk;
+            const Tri4 *pk = &S.packets[pki];
             const Tri4 *pk_l = reinterpret_cast<const Tri4 *>(lds_nodes + (size_t)n_lds * kLdsNodeStride) + (pk_lds ? pki : 0u);
-            uint4 meta;  // active, mask_and, mask_or, masks[0]
-            if (pk_lds) { meta = *reinterpret_cast<const uint4 *>(&pk_l->active); asm volatile("" : "+v"(meta.x)); }
-            else meta = *reinterpret_cast<const uint4 *>(&pk->active);
-            uint32_t m;                                                         // triangle.rs:257-271
-            if (rmask & meta.y) m = meta.x;
-            else if ((rmask & meta.z) == 0) m = 0;
-            else {
-              m = 0;
+            uint4 prim4;
+            uint32_t normal_ok, m;
+            float4 A_x, A_y, A_z, B_x, B_y, B_z, C_x, C_y, C_z;
+            auto load_vertices = [&](const Tri4 *q) {
+              const float4 *pl = reinterpret_cast<const float4 *>(q);
+              A_x = pl[0 + kx]; A_y = pl[0 + ky]; A_z = pl[0 + kz];
+              B_x = pl[3 + kx]; B_y = pl[3 + ky]; B_z = pl[3 + kz];
+              C_x = pl[6 + kx]; C_y = pl[6 + ky]; C_z = pl[6 + kz];
+            };
+            if (!LEAN) {
+              // The packet whole — nine vertex planes in the ray's Woop order, primitive ids, masks, normal-ok bits: twelve
+              // 16-byte loads requested together and waited for once. (Fetched as needed — masks, then vertices behind
+              // the mask test, then ids — a packet step is three dependent round trips; the mask test rejects next to
+              // nothing.) Costs 12 more live registers than the staged form below.
+              uint4 meta, mtail;  // active, mask_and, mask_or, masks[0] | masks[1..3], normal_ok
+              auto load_packet = [&](const Tri4 *q) {
+                load_vertices(q);
+                const uint4 *pw = reinterpret_cast<const uint4 *>(q);
+                prim4 = pw[9]; meta = pw[10]; mtail = pw[11];
+              };
+#define CRT_PACKET_ARRIVED                                                                                          \
+  asm volatile("" : "+v"(A_x.x), "+v"(A_y.x), "+v"(A_z.x), "+v"(B_x.x), "+v"(B_y.x), "+v"(B_z.x), "+v"(C_x.x), \
+               "+v"(C_y.x), "+v"(C_z.x), "+v"(prim4.x), "+v"(meta.x), "+v"(mtail.x))
+              if (pk_lds) { load_packet(pk_l); CRT_PACKET_ARRIVED; }
+              else { load_packet(pk); CRT_PACKET_ARRIVED; }
+#undef CRT_PACKET_ARRIVED
+              normal_ok = mtail.w;
+              if (rmask & meta.y) m = meta.x;                                    // triangle.rs:257-271
+              else if ((rmask & meta.z) == 0) m = 0;
+              else {
+                const uint32_t lane_mask[4] = {meta.w, mtail.x, mtail.y, mtail.z};
+                m = 0;
 #pragma unroll
-              for (int l = 0; l < 4; l++)
-                if ((meta.x & (1u << l)) && ((pk_lds ? pk_l->masks[l] : pk->masks[l]) & rmask)) m |= 1u << l;
+                for (int l = 0; l < 4; l++)
+                  if ((meta.x & (1u << l)) && (lane_mask[l] & rmask)) m |= 1u << l;
+              }
+            } else {
+              // Staged form (the 128-register kernels): masks first, vertices and ids behind the mask test.
+              uint4 meta;  // active, mask_and, mask_or, masks[0]
+              if (pk_lds) { meta = *reinterpret_cast<const uint4 *>(&pk_l->active); asm volatile("" : "+v"(meta.x)); }
+              else meta = *reinterpret_cast<const uint4 *>(&pk->active);
+              if (rmask & meta.y) m = meta.x;                                    // triangle.rs:257-271
+              else if ((rmask & meta.z) == 0) m = 0;
+              else {
+                m = 0;
+#pragma unroll
+                for (int l = 0; l < 4; l++)
+                  if ((meta.x & (1u << l)) && ((pk_lds ? pk_l->masks[l] : pk->masks[l]) & rmask)) m |= 1u << l;
+              }
+              if (m != 0) {
+                // primitive ids and the normal-ok bits ride along with the vertex loads: fetched at the point of use
+                // they would be up to four more dependent round trips per packet, one per accepted lane
+                auto load_rest = [&](const Tri4 *q) {
+                  prim4 = *reinterpret_cast<const uint4 *>(q->prim);
+                  normal_ok = q->normal_ok;
+                  load_vertices(q);
+                };
+                if (pk_lds) { load_rest(pk_l); asm volatile("" : "+v"(A_x.x), "+v"(B_x.x), "+v"(C_x.x), "+v"(prim4.x)); }
+                else load_rest(pk);
+              }
             }
             if (m != 0) {
               CRT_PHASE(3)
@@ -453,25 +517,6 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
               r.ox = g0.x; r.oy = g0.y; r.oz = g0.z;
               r.kx = kx; r.ky = ky; r.kz = kz; r.sx = g1.w; r.sy = g2.x; r.sz = g2.y;
               r.okx = sel3(g0.x, g0.y, g0.z, kx); r.oky = sel3(g0.x, g0.y, g0.z, ky); r.okz = sel3(g0.x, g0.y, g0.z, kz);
-              // primitive ids and the normal-ok bits ride along with the vertex loads: fetched at the point of use they
-              // would be up to four more dependent round trips per packet, one per accepted lane
-              uint4 prim4;
-              uint32_t normal_ok;
-              float4 A_x, A_y, A_z, B_x, B_y, B_z, C_x, C_y, C_z;
-              auto load_packet = [&](const Tri4 *q) {
-                prim4 = *reinterpret_cast<const uint4 *>(q->prim);
-                normal_ok = q->normal_ok;
-                const float4 *pl = reinterpret_cast<const float4 *>(&q->v[0][0][0]);
-                A_x = pl[0 + kx]; A_y = pl[0 + ky]; A_z = pl[0 + kz];
-                B_x = pl[3 + kx]; B_y = pl[3 + ky]; B_z = pl[3 + kz];
-                C_x = pl[6 + kx]; C_y = pl[6 + ky]; C_z = pl[6 + kz];
-              };
-              if (pk_lds) {  // two arms, as for the nodes: merged they become FLAT loads through a generic pointer
-                load_packet(pk_l);
-                asm volatile("" : "+v"(A_x.x), "+v"(B_x.x), "+v"(C_x.x), "+v"(prim4.x));
-              } else {
-                load_packet(pk);
-              }
               const uint32_t prim_of[4] = {prim4.x, prim4.y, prim4.z, prim4.w};
               const float vax[4] = {A_x.x, A_x.y, A_x.z, A_x.w}, vay[4] = {A_y.x, A_y.y, A_y.z, A_y.w},
                           vaz[4] = {A_z.x, A_z.y, A_z.z, A_z.w};
@@ -590,10 +635,10 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
         uint32_t rem = aux >> 8;  // 24 bits: a leaf's scalar list is not limited to 255 entries (make_leaf fallbacks)
         float closest = g0.w;
         const float dx = rd(side_d, row, 0), dy = rd(side_d, row, 1), dz = rd(side_d, row, 2), time = rd(side_d, row, 3);
-        const uint32_t pi = S.indices[cursor];
+        bool occluded = false;
+        const uint32_t pi = (CRT_DIRECT_INST && direct_leaves && (cursor & kIndexInstance)) ? cursor : S.indices[cursor];
         cursor++;
         rem--;
-        bool occluded = false;
         if (pi & kIndexInstance) {  // prim.rs:345-378 — the list entry IS the instance record's slot
           const uint32_t inst = pi & ~kIndexInstance;
           const DevInstance *in = &S.instances[inst];
@@ -602,7 +647,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
             if (level + 1 >= (uint32_t)kMaxLevels) err |= 2u;
             else {
               float w2l[12];
-              if ((ih.y & 2u) && time > 0.0f) motion_w2l(*in, time, w2l);
+              if ((ih.y & 2u) && time > 0.0f) motion_w2l(*reinterpret_cast<const DevInstanceMotion *>(S.normals + (ih.y >> 2)), time, w2l);
               else {
 #pragma unroll
                 for (int i = 0; i < 12; i++) w2l[i] = in->w2l[i];
@@ -624,9 +669,18 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
               // a node step and an exit step (each a scheduling round at a third of the lanes) for nothing.
               bool enter = true;
               if (CRT_ROOT_REJECT && DIRECT) {  // the instance-heavy engine only: on cornellbox (two placements) the test costs 1.5 % and rejects little
-                const float4 *nb = reinterpret_cast<const float4 *>(&S.nodes[ih.x]);
-                const float4 mnx = nb[0], mny = nb[1], mnz = nb[2], mxx = nb[3], mxy = nb[4], mxz = nb[5];
-                const uint4 ch = *reinterpret_cast<const uint4 *>(nb + 6);
+                float4 mnx, mny, mnz, mxx, mxy, mxz;
+                uint4 ch;
+                if (CRT_LDS_ROOT && ih.x < n_lds) {  // the instanced trees' roots are numbered into the LDS window (scene.cpp)
+                  const float4 *nb = reinterpret_cast<const float4 *>(lds_nodes + (size_t)ih.x * kLdsNodeStride);
+                  mnx = nb[0]; mny = nb[1]; mnz = nb[2]; mxx = nb[3]; mxy = nb[4]; mxz = nb[5];
+                  ch = *reinterpret_cast<const uint4 *>(nb + 6);
+                  asm volatile("" : "+v"(mnx.x), "+v"(mxx.x), "+v"(ch.x));  // two arms, as in the node phase
+                } else {
+                  const float4 *nb = reinterpret_cast<const float4 *>(&S.nodes[ih.x]);
+                  mnx = nb[0]; mny = nb[1]; mnz = nb[2]; mxx = nb[3]; mxy = nb[4]; mxz = nb[5];
+                  ch = *reinterpret_cast<const uint4 *>(nb + 6);
+                }
                 const float TINY = 1e-20f, HUGE_ = 1e20f;  // safe_inv3 (bvh.rs:662-668), as setup_ray
                 const float ix = absf(qx) < TINY ? copysgn(HUGE_, qx) : 1.0f / qx;
                 const float iy = absf(qy) < TINY ? copysgn(HUGE_, qy) : 1.0f / qy;
@@ -769,7 +823,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
             bnx = rd(side_n, row, 0); bny = rd(side_n, row, 1); bnz = rd(side_n, row, 2);
             bprim = __float_as_uint(rd(side_n, row, 3));
           }
-          instance_normal(S.instances[f.inst], time, bnx, bny, bnz);
+          instance_normal(S, f.inst, time, bnx, bny, bnz);
           wr(side_n, row, 0, bnx); wr(side_n, row, 1, bny); wr(side_n, row, 2, bnz);
           wr(side_n, row, 3, __uint_as_float(bprim));
           // the hit is attributed to the instance's geometry id; prim_id stays the inner one
@@ -814,7 +868,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
           }
           const uint32_t binst = rd(best, row, B_BINST);
           if (CRT_DEFER_NORMAL && binst != kInvalid) {  // the hit lies in a level-1 instance: its normal is still local
-            instance_normal(S.instances[binst], rd(side_d, row, 3), hit.nx, hit.ny, hit.nz);
+            instance_normal(S, binst, rd(side_d, row, 3), hit.nx, hit.ny, hit.nz);
             hit.geom = rd(best, row, B_BGEOM);  // the instance's geometry id; prim_id stays the inner one
           }
         }
@@ -837,25 +891,34 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
 #ifndef CRT_POOL_ROWS
 #define CRT_POOL_ROWS 2
 #endif
-#ifndef CRT_POOL_NODES
-#define CRT_POOL_NODES 72
-#endif
-constexpr int kPoolNodes = CRT_POOL_NODES;  // nodes of the top of the tree staged in LDS per workgroup (flat scenes)
-#ifndef CRT_POOL_NODES_DEEP
-#define CRT_POOL_NODES_DEEP 16
-#endif
-constexpr int kPoolNodesDeep = CRT_POOL_NODES_DEEP;  // ... with the deep stack: 16 still fit three workgroups per CU (+0.4 %); 24 do not (-33 %)
+constexpr int kPoolNodes = CRT_POOL_NODES;          // nodes staged in LDS per workgroup, flat scenes (crt_internal.h)
+constexpr int kPoolNodesDeep = CRT_POOL_NODES_DEEP;  // ... with the deep stack
 constexpr int kEngineLdsFlat = (kBlock / 64) * pool_lds_dwords<CRT_POOL_ROWS>(kPoolStack) + kPoolNodes * kLdsNodeStride;
 constexpr int kEngineLdsDeep = (kBlock / 64) * pool_lds_dwords<CRT_POOL_ROWS>(kPoolStackDeep) + kPoolNodesDeep * kLdsNodeStride;
 constexpr int kEngineLdsDwords = kEngineLdsFlat > kEngineLdsDeep ? kEngineLdsFlat : kEngineLdsDeep;
-// Runs the traversal for one workgroup. `lds` = kEngineLdsDwords dwords, 16-byte aligned. Contains a workgroup
-// barrier: call from uniform control flow, after the shared variables the callbacks use are initialised.
-template <bool ANY, bool STATS, class Fetch, class Emit>
+// WIDE: the split for kernels that run FOUR workgroups per CU (four waves per SIMD: 128 registers, 40 KB of LDS each)
+// instead of three — four stack entries per ray in LDS, an eight-node window, the staged packet loads. On flat scenes
+// the fourth wave per SIMD buys more than the shorter LDS stack and the 25 spilled registers cost (cornellbox +3 %,
+// veach_mis +6 %, sun_sky +7 % for the per-stage pipeline on it over the fused kernel on three; an instanced city,
+// whose rays stack the parent's entries under the instance's, loses 6 %: profiles/README.md). The renderer and the
+// batched queries pick it per scene (DevScene::pool_stack below the deep split).
+#ifndef CRT_POOL_STACK_WIDE
+#define CRT_POOL_STACK_WIDE 4
+#endif
+constexpr int kPoolStackWide = CRT_POOL_STACK_WIDE;
+constexpr int kPoolNodesWide = CRT_POOL_NODES_WIDE;  // crt_internal.h
+constexpr int kEngineLdsWide = (kBlock / 64) * pool_lds_dwords<CRT_POOL_ROWS>(kPoolStackWide) + kPoolNodesWide * kLdsNodeStride;
+static_assert(kEngineLdsWide * 4 + 1024 <= 40 * 1024, "four workgroups of the wide split per CU");
+// Runs the traversal for one workgroup. `lds` = kEngineLdsDwords dwords (WIDE: kEngineLdsWide), 16-byte aligned.
+// Contains a workgroup barrier: call from uniform control flow, after the shared variables the callbacks use are
+// initialised.
+template <bool ANY, bool STATS, bool WIDE, class Fetch, class Emit>
 __device__ __forceinline__ void run_traversal(const DevScene &S, uint32_t *lds, float t_min, uint32_t &err, LaneStats &st,
                                               Fetch fetch, Emit emit) {
   // the split of the arena is the scene's (uniform): clamp to what the arena was sized for
-  const uint32_t pstack = S.pool_stack >= (uint32_t)kPoolStackDeep ? (uint32_t)kPoolStackDeep : (uint32_t)kPoolStack;
-  const int pnodes = pstack == (uint32_t)kPoolStackDeep ? kPoolNodesDeep : kPoolNodes;
+  const uint32_t pstack = WIDE ? (uint32_t)kPoolStackWide
+                               : (S.pool_stack >= (uint32_t)kPoolStackDeep ? (uint32_t)kPoolStackDeep : (uint32_t)kPoolStack);
+  const int pnodes = WIDE ? kPoolNodesWide : (pstack == (uint32_t)kPoolStackDeep ? kPoolNodesDeep : kPoolNodes);
   const int wave_dwords = pool_lds_dwords<CRT_POOL_ROWS>((int)pstack);
   uint32_t *lds_nodes = lds + (kBlock / 64) * wave_dwords;
   uint32_t n_lds_pk;
@@ -866,9 +929,9 @@ __device__ __forceinline__ void run_traversal(const DevScene &S, uint32_t *lds, 
   // the root test 1.5 % (profiles/README.md).
   uint32_t *wave_lds = lds + (threadIdx.x >> 6) * wave_dwords;
   if (CRT_DIRECT_LEAVES != 0 && S.direct_leaves != 0)
-    traverse_pool<ANY, STATS, CRT_POOL_ROWS, true>(S, wave_lds, t_min, lds_nodes, n_lds, n_lds_pk, pstack, err, st, fetch, emit);
+    traverse_pool<ANY, STATS, CRT_POOL_ROWS, true, WIDE>(S, wave_lds, t_min, lds_nodes, n_lds, n_lds_pk, pstack, err, st, fetch, emit);
   else
-    traverse_pool<ANY, STATS, CRT_POOL_ROWS, false>(S, wave_lds, t_min, lds_nodes, n_lds, n_lds_pk, pstack, err, st, fetch, emit);
+    traverse_pool<ANY, STATS, CRT_POOL_ROWS, false, WIDE>(S, wave_lds, t_min, lds_nodes, n_lds, n_lds_pk, pstack, err, st, fetch, emit);
 }
 
 }  // namespace dev

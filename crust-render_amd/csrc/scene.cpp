@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cmath>
 #include <cstring>
+#include <algorithm>
+#include <utility>
 #include <unordered_map>
 
 #include <cstdlib>
@@ -184,6 +186,7 @@ struct Flat {
   std::vector<uint32_t> indices;
   std::vector<DevPrim> prims;
   std::vector<DevInstance> instances;
+  std::vector<std::pair<uint32_t, DevInstanceMotion>> moving;  // (instance slot, placements): appended to `normals` at upload
   std::vector<float> normals;
   struct Placed { uint32_t root; uint32_t has_packets; };
   std::unordered_map<const Scene *, Placed> placed;
@@ -226,7 +229,19 @@ Flat::Placed place(Flat &f, const Scene &s) {
       if (p.active & (1u << l)) p.prim[l] += prim0;
     f.packets.push_back(p);
   }
+  // Instance slots in the order of the scalar lists (= the builder's leaf order, spatially coherent): the placements
+  // of one leaf sit in consecutive slots, which is what the direct-instance leaf word needs (crt_internal.h).
   std::vector<uint32_t> inst_slot(b.prims.size(), CRT_INVALID_ID);
+  {
+    uint32_t next_slot = uint32_t(f.instances.size());
+    static const bool list_order = [] { const char *e = getenv("CRT_INST_ORDER"); return !e || atoi(e) != 0; }();  // A/B runs
+    if (list_order)
+    for (uint32_t i : b.indices)
+      if (b.prims[i].kind == PRIM_INSTANCE && inst_slot[i] == CRT_INVALID_ID) inst_slot[i] = next_slot++;
+    for (size_t i = 0; i < b.prims.size(); i++)  // on no list (cannot happen with this builder): still gets a record
+      if (b.prims[i].kind == PRIM_INSTANCE && inst_slot[i] == CRT_INVALID_ID) inst_slot[i] = next_slot++;
+    f.instances.resize(next_slot);
+  }
   for (size_t i = 0; i < b.prims.size(); i++) {
     const Prim &p = b.prims[i];
     DevPrim d{};
@@ -253,11 +268,14 @@ Flat::Placed place(Flat &f, const Scene &s) {
       in.flags = (inner[i].has_packets ? 1u : 0u) | (p.has_end ? 2u : 0u);
       in.geom_id = p.geom_id;
       in.mask = p.mask;
-      put_affine(in.l2w, p.l2w);
-      put_affine(in.l2w_end, p.has_end ? p.l2w_end : p.l2w);
-      inst_slot[i] = uint32_t(f.instances.size());
       d.d[0] = u2f(inst_slot[i]);
-      f.instances.push_back(in);
+      f.instances[inst_slot[i]] = in;
+      if (p.has_end) {
+        DevInstanceMotion mo{};
+        put_affine(mo.l2w, p.l2w);
+        put_affine(mo.l2w_end, p.l2w_end);
+        f.moving.emplace_back(inst_slot[i], mo);
+      }
     }
     f.prims.push_back(d);
   }
@@ -275,30 +293,58 @@ int Scene::ensure_device() {
   if (!device_ok()) return CRT_ERR_NO_DEVICE;
   Flat f;
   Flat::Placed me = place(f, *this);
-  // Renumber the nodes breadth-first, the queried scene's tree first, then the instanced trees: the first K
-  // nodes of the array are then the top levels of the top-level tree — the window the kernels stage in LDS.
-  // Node numbers are opaque to traversal (children are visited by lane order and distance), so results and
-  // visit order do not change.
+  // kernels/traverse_pool.hip.h: the engine's LDS split. Deep stacks pay where rays spend their time inside
+  // instances (thousands of placements); a handful of placements under a real top-level tree is still a flat scene.
+  const bool many_instances = f.instances.size() >= 64;
+  uint32_t pool_stack = many_instances ? 10u : 6u;
+  if (const char *e = getenv("CRT_POOL_STACK_RT")) pool_stack = (uint32_t)atoi(e);  // A/B runs
+  const bool deep = pool_stack >= 10u;  // run_traversal's rule for the window size
+  // Renumber the nodes for the window the kernels stage in LDS (the first CRT_POOL_NODES / _DEEP nodes of the
+  // array): the top levels of the queried scene's tree breadth-first, then the ROOTS of the instanced trees, most
+  // placed first — every instance entry tests its tree's root (a city of 40 000 placements has 8 of them and a ray
+  // meets five per traversal), so they earn their slots before the third level of the top-level tree does — then
+  // the rest of the top-level tree and the instanced trees, breadth-first. Node numbers are opaque to traversal
+  // (children are visited by lane order and distance), so results and visit order do not change.
   if (!f.nodes.empty()) {
-    std::vector<uint32_t> roots;
-    if (me.root != CRT_INVALID_ID) roots.push_back(me.root);
-    for (const DevInstance &in : f.instances)
-      if (in.root != CRT_INVALID_ID) roots.push_back(in.root);
     std::vector<uint32_t> new_idx(f.nodes.size(), CRT_INVALID_ID), order;
     order.reserve(f.nodes.size());
-    for (uint32_t r : roots) {
-      if (new_idx[r] != CRT_INVALID_ID) continue;
-      size_t head = order.size();
-      new_idx[r] = uint32_t(order.size());
-      order.push_back(r);
-      while (head < order.size()) {
+    auto number = [&](uint32_t n) {
+      if (new_idx[n] != CRT_INVALID_ID) return;
+      new_idx[n] = uint32_t(order.size());
+      order.push_back(n);
+    };
+    auto bfs_from = [&](size_t head, size_t stop_at) {  // expands order[head ..) until `stop_at` nodes are numbered
+      while (head < order.size() && order.size() < stop_at) {
         const WideNode &n = f.nodes[order[head++]];
-        for (int l = 0; l < 4; l++) {
-          if (!(n.flags & (1u << l)) || (n.flags & (1u << (4 + l)))) continue;
-          const uint32_t c = n.child[l];
-          if (new_idx[c] == CRT_INVALID_ID) { new_idx[c] = uint32_t(order.size()); order.push_back(c); }
-        }
+        for (int l = 0; l < 4; l++)
+          if ((n.flags & (1u << l)) && !(n.flags & (1u << (4 + l)))) number(n.child[l]);
       }
+      return head;
+    };
+    std::vector<std::pair<uint32_t, uint32_t>> inner_roots;  // (placements, root), distinct
+    {
+      std::unordered_map<uint32_t, uint32_t> count;
+      for (const DevInstance &in : f.instances)
+        if (in.root != CRT_INVALID_ID) count[in.root]++;
+      for (const auto &kv : count) inner_roots.emplace_back(kv.second, kv.first);
+      std::sort(inner_roots.begin(), inner_roots.end(), [](const auto &a, const auto &b) {
+        return a.first != b.first ? a.first > b.first : a.second < b.second;
+      });
+    }
+    const size_t window = deep ? CRT_POOL_NODES_DEEP : CRT_POOL_NODES;
+    size_t n_staged_roots = std::min(inner_roots.size(), window / 2);
+    if (const char *e = getenv("CRT_STAGE_ROOTS")) n_staged_roots = std::min(n_staged_roots, (size_t)atoi(e));  // A/B runs
+    size_t head = 0;
+    if (me.root != CRT_INVALID_ID) {
+      number(me.root);
+      head = bfs_from(0, window - n_staged_roots);
+    }
+    for (size_t k = 0; k < n_staged_roots; k++) number(inner_roots[k].second);
+    // the rest: nodes numbered but not yet expanded are expanded in numbering order, tree after tree
+    head = bfs_from(head, f.nodes.size() + 1);
+    for (const auto &r : inner_roots) {
+      number(r.second);
+      head = bfs_from(head, f.nodes.size() + 1);
     }
     std::vector<WideNode> renum(order.size());
     for (size_t k = 0; k < order.size(); k++) {
@@ -315,25 +361,50 @@ int Scene::ensure_device() {
   // Device form of a node's child words: leaf children carry the leaf tag (bit 31), empty lanes are CRT_INVALID_ID,
   // so the traversal derives everything from the word it has to load anyway and never touches `flags`.
   // child words carry node and leaf indices below their tag bits (crt_internal.h)
-  if (f.nodes.size() >= (size_t(1) << 31) || f.leaves.size() >= (size_t(1) << 30)) {
-    set_error_text("scene image: %zu nodes / %zu leaves exceed the child word's index range", f.nodes.size(), f.leaves.size());
+  if (f.nodes.size() >= (size_t(1) << 31) || f.leaves.size() >= (size_t(1) << 30) || f.indices.size() >= (size_t(1) << 31)) {
+    set_error_text("scene image: %zu nodes / %zu leaves / %zu list entries exceed the child word's index range",
+                   f.nodes.size(), f.leaves.size(), f.indices.size());
     return CRT_ERR_UNSUPPORTED;
   }
-  bool direct = f.instances.size() >= 64 || f.packets.empty();
+  bool direct = many_instances || f.packets.empty();
   if (const char *e = getenv("CRT_DIRECT_LEAVES")) direct = atoi(e) != 0;  // A/B runs
   if (!CRT_DIRECT_LEAVES) direct = false;  // an engine built without the direct form must never meet one
+  bool direct_inst = CRT_DIRECT_INST != 0;
+  if (const char *e = getenv("CRT_DIRECT_INST")) direct_inst = direct_inst && atoi(e) != 0;  // A/B runs
   for (WideNode &n : f.nodes)
     for (int l = 0; l < 4; l++) {
       if (!(n.flags & (1u << l))) n.child[l] = CRT_INVALID_ID;
       else if (n.flags & (1u << (4 + l))) {
         const Leaf &lf = f.leaves[n.child[l]];
-        if (direct && lf.pkt_count == 0 && lf.idx_count >= 1 && lf.idx_count <= 3 && lf.idx_first < (1u << 28))
-          n.child[l] = 0x80000000u | kDirectLeafTag | (lf.idx_count << 28) | lf.idx_first;
-        else
-          n.child[l] |= 0x80000000u;
+        if (direct && lf.pkt_count == 0 && lf.idx_count >= 1 && lf.idx_count <= 3) {
+          // instances in consecutive slots (what place() makes of a leaf of instances): the word names the first slot
+          const uint32_t e0 = f.indices[lf.idx_first];
+          bool run = direct_inst && (e0 & kIndexInstance) && ((e0 & ~kIndexInstance) + lf.idx_count <= kDirectIndexMask);
+          for (uint32_t k = 1; run && k < lf.idx_count; k++) run = f.indices[lf.idx_first + k] == e0 + k;
+          if (run) {
+            n.child[l] = 0x80000000u | kDirectLeafTag | (lf.idx_count << 28) | kDirectInstTag | (e0 & ~kIndexInstance);
+            continue;
+          }
+          if (lf.idx_first <= kDirectIndexMask) {
+            n.child[l] = 0x80000000u | kDirectLeafTag | (lf.idx_count << 28) | lf.idx_first;
+            continue;
+          }
+        }
+        n.child[l] |= 0x80000000u;
       }
     }
   auto img = std::make_unique<DeviceImage>();
+  // placements of the moving instances: behind the shading normals, addressed through the instance's flags word
+  for (const auto &mv : f.moving) {
+    const size_t at = (f.normals.size() + 3) & ~size_t(3);  // 16-byte aligned
+    if (at + 24 >= (size_t(1) << 30)) {
+      set_error_text("scene image: %zu normal floats leave no room to address a moving instance's placements", f.normals.size());
+      return CRT_ERR_UNSUPPORTED;
+    }
+    f.normals.resize(at + 24);
+    std::memcpy(&f.normals[at], &mv.second, sizeof(DevInstanceMotion));
+    f.instances[mv.first].flags |= uint32_t(at) << 2;
+  }
   constexpr int NA = 7;
   const size_t sz[NA] = {f.nodes.size() * sizeof(WideNode), f.leaves.size() * sizeof(Leaf),
                          f.packets.size() * sizeof(Tri4),   f.indices.size() * sizeof(uint32_t),
@@ -368,10 +439,7 @@ int Scene::ensure_device() {
   img->view.n_nodes = uint32_t(f.nodes.size());
   img->view.n_packets = uint32_t(f.packets.size());
   img->view.direct_leaves = direct ? 1u : 0u;
-  // kernels/traverse_pool.hip.h: the engine's LDS split. Deep stacks pay where rays spend their time inside
-  // instances (thousands of placements); a handful of placements under a real top-level tree is still a flat scene.
-  img->view.pool_stack = f.instances.size() >= 64 ? 10u : 6u;
-  if (const char *e = getenv("CRT_POOL_STACK_RT")) img->view.pool_stack = (uint32_t)atoi(e);  // A/B runs
+  img->view.pool_stack = pool_stack;
   dev = std::move(img);
   return CRT_OK;
 }

@@ -268,10 +268,14 @@ int crt_render_stats(CrtRenderer *r, CrtRayStats *out);
  * executions that contained a vertex of the class and how many of their 64 lanes held one. out_* (both or neither):
  * the counts since the last read, which also clears them. lanes / (64 * waves) is the class's lane utilisation. */
 int crt_renderer_shade_class_stats(CrtRenderer *r, int enable, uint64_t out_waves[4], uint64_t out_lanes[4]);
+/* The launch pipeline this renderer chose for its scene: out[0] = 1 fused (one launch runs generate and every
+ * bounce's extend, shade and shadow stage of a batch; instance-heavy and sphere-only scenes), 0 one launch per stage
+ * and bounce; out[1] = 1 when the traversal kernels are the four-workgroups-per-CU instances (flat triangle scenes);
+ * out[2] = workgroups (= queue segments) per launch. Environment CRT_FUSED / CRT_WIDE / CRT_GRID_MULT override. */
+int crt_renderer_pipeline(const CrtRenderer *r, uint32_t out[3]);
 /* Live HIP-event timing of the kernels launched by crt_render_samples since the last reset, by class:
- * 0 = extend (closest-hit traversal) — or, by default, the fused path-loop kernel that runs generate, extend, shade
- * and shadow of a whole batch in one launch (environment CRT_FUSED=0 launches every stage separately) —
- * 1 = shade, 2 = shadow (occlusion traversal), 3 = other.
+ * 0 = extend (closest-hit traversal) — or, in the fused pipeline, the path-loop kernel that runs generate, extend,
+ * shade and shadow of a whole batch in one launch — 1 = shade, 2 = shadow (occlusion traversal), 3 = other.
  * out_ms[k] = summed duration, out_launches[k] = launches. Enabled by crt_renderer_profile(r, 1). */
 int crt_renderer_profile(CrtRenderer *r, int enable);
 int crt_renderer_profile_read(CrtRenderer *r, double out_ms[4], uint64_t out_launches[4]);

@@ -10,7 +10,7 @@ launches = collections.defaultdict(lambda: collections.defaultdict(set))
 for d in sorted(glob.glob(f"gpurun_out/pmc_{tag}_*/*/*_counter_collection.csv")):
     for r in csv.DictReader(open(d)):
         name = r["Kernel_Name"]
-        m = re.search(r"(k_\w+)(<\w+>)?", name)
+        m = re.search(r"(k_\w+)(<[^>]*>)?", name)
         k = (m.group(1) + (m.group(2) or "")) if m else re.sub(r"[^A-Za-z0-9_:<>]", "", name)[:60]
         out[k][r["Counter_Name"]] += float(r["Counter_Value"])
         launches[k][r["Counter_Name"]].add((d, r["Dispatch_Id"]))  # a counter may come as several rows per dispatch
@@ -41,5 +41,7 @@ for k, c in out.items():
         e["valu_active_frac"] = c.get("SQ_ACTIVE_INST_VALU", 0) / c["SQ_WAVE_CYCLES"]
         e["wait_any_frac"] = c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"]
         e["wait_inst_frac"] = c.get("SQ_WAIT_INST_ANY", 0) / c["SQ_WAVE_CYCLES"]
+        if "SQ_ACTIVE_INST_ANY" in c:
+            e["inst_active_frac"] = c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"]
     res[k] = e
 print(json.dumps(res, indent=1))

@@ -75,13 +75,18 @@ def test_random_world_renders_identically(crt, seed):
     assert bad.shape[0] == 0, (seed, bad.shape[0], bad[:3])
 
 
-@pytest.mark.parametrize("split", ["6", "10"])
+@pytest.mark.parametrize("split", ["6", "10", "wide"])
 def test_both_lds_splits_of_the_engine_match_the_oracle(crt, split, monkeypatch):
     """The traversal engine divides its LDS between stack entries and the node window per scene (6 + 72 nodes, or
-    10 + 2 for instance-heavy scenes, scene.cpp). Forcing each split (CRT_POOL_STACK_RT, read when the device image
-    is built) over scenes with nested instances: hits and occlusion flags identical to the oracle."""
+    10 + 16 for instance-heavy scenes, scene.cpp; 4 + 8 in the kernels that run four workgroups per CU). Forcing each
+    split (CRT_POOL_STACK_RT, read when the device image is built; CRT_WIDE) over scenes with nested instances: hits and
+    occlusion flags identical to the oracle."""
     import torch
-    monkeypatch.setenv("CRT_POOL_STACK_RT", split)
+    if split == "wide":  # the four-workgroups-per-CU kernels (4 LDS stack entries), which flat scenes get by default
+        monkeypatch.setenv("CRT_WIDE", "1")
+    else:
+        monkeypatch.setenv("CRT_WIDE", "0")
+        monkeypatch.setenv("CRT_POOL_STACK_RT", split)
     for seed in (13, 16, 18):
         recipe = fuzz_scenes.recipe(seed)
         o_scene, _ok = fuzz_scenes.build(ora, recipe)

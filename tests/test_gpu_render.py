@@ -163,26 +163,34 @@ def test_tile_shards_reassemble_the_single_gpu_image(crt):
     assert np.array_equal(img.reshape(48, 80, 3).view(np.uint32), full.image().view(np.uint32))
 
 
-def test_fused_and_per_stage_launches_agree(crt, tmp_path):
-    """The fused path-loop kernel (default) and the one-launch-per-stage path (CRT_FUSED=0) are the same device
-    functions: identical image and counters, on a lit scene with interior media."""
+@pytest.mark.parametrize("scene,w,h,depth", [("openpbr_showcase", 96, 54, 12), ("cornellbox", 96, 54, 8),
+                                             ("nested_instancing", 64, 36, 6)])
+def test_the_three_pipelines_agree(crt, tmp_path, scene, w, h, depth):
+    """The renderer picks its pipeline per scene (pathtrace.hip, Renderer::fused): the fused path-loop kernel on three
+    workgroups per CU for instance-heavy scenes, one launch per stage with the four-workgroups-per-CU traversal kernels
+    for flat ones. All three combinations (fused; per-stage with either engine split) are the same device functions:
+    identical image and counters on a lit scene with interior media, a triangle scene and nested instances."""
     import subprocess
     import sys
     code = (
         "import os, sys, numpy as np; sys.path.insert(0, %r); import torch\n"
         "from __graft_entry__ import load_package; crt = load_package()\n"
-        "r, _ = crt.load_usda(os.path.join(%r, 'scenes', 'openpbr_showcase.usda'), 96, 54, 12)\n"
+        "r, _ = crt.load_usda(os.path.join(%r, 'scenes', %r + '.usda'), %d, %d, %d)\n"
         "r.render_samples(0, 8); torch.cuda.synchronize(); st = r.stats()\n"
-        "np.save(sys.argv[1], r.image()); print(st.closest_hit, st.shadow_rays, st.vertices, st.rr_killed)\n" % (ROOT, ROOT))
+        "np.save(sys.argv[1], r.image()); print(st.closest_hit, st.shadow_rays, st.vertices, st.rr_killed)\n"
+        % (ROOT, ROOT, scene, w, h, depth))
     outs = []
-    for fused in ("1", "0"):
-        path = str(tmp_path / ("img%s.npy" % fused))
-        env = dict(os.environ, CRT_FUSED=fused)
-        res = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=300)
-        assert res.returncode == 0, res.stderr[-2000:]
+    for tag, env in (("fused", dict(CRT_FUSED="1")), ("stage3", dict(CRT_FUSED="0", CRT_WIDE="0")),
+                     ("stage4", dict(CRT_FUSED="0", CRT_WIDE="1"))):
+        path = str(tmp_path / ("img_%s.npy" % tag))
+        res = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True, text=True,
+                             timeout=300)
+        assert res.returncode == 0, (tag, res.stderr[-2000:])
         outs.append((np.load(path), res.stdout.strip().splitlines()[-1]))
-    assert outs[0][1] == outs[1][1]
-    assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
+    for img, line in outs[1:]:
+        assert line == outs[0][1]
+        assert np.array_equal(img.view(np.uint32), outs[0][0].view(np.uint32))
+    assert int(outs[0][1].split()[0]) > w * h * 8  # bounces happened
 
 
 def test_render_report_counts_the_scene_and_the_rays(crt, tmp_path):
