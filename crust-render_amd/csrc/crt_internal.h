@@ -171,7 +171,7 @@ constexpr uint32_t kDirectIndexMask = 0x07ffffffu;
 // Nodes of the top of the tree the traversal kernels stage in LDS per workgroup (kernels/traverse_pool.hip.h): the
 // upload numbers the nodes for this window.
 #ifndef CRT_POOL_NODES_WIDE
-#define CRT_POOL_NODES_WIDE 8   // the four-workgroups-per-CU kernels (flat scenes)
+#define CRT_POOL_NODES_WIDE 26  // the four-workgroups-per-CU kernels (small flat scenes)
 #endif
 #ifndef CRT_DIRECT_INST
 #define CRT_DIRECT_INST 1  // 0: the direct-instance form is neither written nor understood (A/B builds)
@@ -186,12 +186,12 @@ constexpr uint32_t kDirectIndexMask = 0x07ffffffu;
 #define CRT_DIRECT_LEAVES 1  // 0: neither written by the upload nor understood by the engine (A/B builds)
 #endif
 
-// Which scenes the four-workgroups-per-CU traversal kernels (kernels/traverse_pool.hip.h, WIDE: four stack entries per
-// ray in LDS) are launched for: flat (not instance-heavy) triangle scenes whose trees are shallow enough for that
+// Which scenes the four-workgroups-per-CU traversal kernels (kernels/traverse_pool.hip.h, WIDE: three stack entries
+// per ray in LDS) are launched for: flat (not instance-heavy) triangle scenes whose trees are shallow enough for that
 // stack. Measured (profiles/README.md): the renderer's per-stage pipeline on them gains 4-9 % on cornellbox, veach_mis,
-// sun_sky (a few hundred nodes); 16 M incoherent rays against 43 200 triangles (3 600 nodes, 15 nodes per ray) lose
-// 7 %, an instanced city 6 %, sphere-only scenes are indifferent.
-inline bool wide_split(const DevScene &s) { return s.pool_stack < 10u && s.n_packets > 0 && s.n_nodes <= 2048u; }
+// sun_sky (at most a few hundred nodes); 16 M incoherent rays against 43 200 triangles (3 600 nodes, 15 nodes per ray)
+// lose 7 %, an instanced city 6 %, sphere-only scenes are indifferent.
+inline bool wide_split(const DevScene &s) { return s.pool_stack < 10u && s.n_packets > 0 && s.n_nodes <= 1024u; }
 
 struct DeviceImage {
   void *blob = nullptr;

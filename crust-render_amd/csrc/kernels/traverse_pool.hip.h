@@ -897,18 +897,19 @@ constexpr int kEngineLdsFlat = (kBlock / 64) * pool_lds_dwords<CRT_POOL_ROWS>(kP
 constexpr int kEngineLdsDeep = (kBlock / 64) * pool_lds_dwords<CRT_POOL_ROWS>(kPoolStackDeep) + kPoolNodesDeep * kLdsNodeStride;
 constexpr int kEngineLdsDwords = kEngineLdsFlat > kEngineLdsDeep ? kEngineLdsFlat : kEngineLdsDeep;
 // WIDE: the split for kernels that run FOUR workgroups per CU (four waves per SIMD: 128 registers, 40 KB of LDS each)
-// instead of three — four stack entries per ray in LDS, an eight-node window, the staged packet loads. On flat scenes
-// the fourth wave per SIMD buys more than the shorter LDS stack and the 25 spilled registers cost (cornellbox +3 %,
-// veach_mis +6 %, sun_sky +7 % for the per-stage pipeline on it over the fused kernel on three; an instanced city,
-// whose rays stack the parent's entries under the instance's, loses 6 %: profiles/README.md). The renderer and the
-// batched queries pick it per scene (DevScene::pool_stack below the deep split).
+// instead of three — three stack entries per ray in LDS, a 26-node window, the staged packet loads (4 + 8: cornellbox
+// equal, veach_mis -1.3 %, sun_sky -1.9 %; 2 + 44: cornellbox -2 %). On small flat scenes the fourth wave per SIMD buys
+// more than the shorter LDS stack and the 30 spilled registers cost (cornellbox +4-6 %, veach_mis +9 %, sun_sky +8 % for
+// the per-stage pipeline on it over the fused kernel on three; an instanced city, whose rays stack the parent's entries
+// under the instance's, loses 6 %: profiles/README.md). The renderer and the batched queries pick it per scene
+// (crt_internal.h, wide_split).
 #ifndef CRT_POOL_STACK_WIDE
-#define CRT_POOL_STACK_WIDE 4
+#define CRT_POOL_STACK_WIDE 3
 #endif
 constexpr int kPoolStackWide = CRT_POOL_STACK_WIDE;
 constexpr int kPoolNodesWide = CRT_POOL_NODES_WIDE;  // crt_internal.h
 constexpr int kEngineLdsWide = (kBlock / 64) * pool_lds_dwords<CRT_POOL_ROWS>(kPoolStackWide) + kPoolNodesWide * kLdsNodeStride;
-static_assert(kEngineLdsWide * 4 + 1024 <= 40 * 1024, "four workgroups of the wide split per CU");
+static_assert(kEngineLdsWide * 4 + 512 <= 40 * 1024, "four workgroups of the wide split per CU");
 // Runs the traversal for one workgroup. `lds` = kEngineLdsDwords dwords (WIDE: kEngineLdsWide), 16-byte aligned.
 // Contains a workgroup barrier: call from uniform control flow, after the shared variables the callbacks use are
 // initialised.
