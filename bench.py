@@ -5,10 +5,10 @@
 
 Workload (config.workload): samples/cornellbox.usda at 1920x1080, scene-default depth 32, triangle filter r=1,
 adaptive stopping off (variance 0), frame 0. A "step" is ONE wavefront batch: `--spp-per-step` samples (default
-128) of every pixel a rank owns — generate, then up to depth+1 rounds of extend / shade / shadow, then the film
-fold — with the scene, the path-state planes (44 GB at this size: batches are sized for 288 GB of HBM — longer queue
-segments drain the traversal's ray pools less often: 64 / 128 / 192 spp per batch measure 7635 / 7811 / 7908 Mray/s) and
-the film resident in HBM before the timed region starts. 1024 spp is 8 such steps, the default K.
+256) of every pixel a rank owns — generate, then up to depth+1 rounds of extend / shade / shadow, then the film
+fold — with the scene, the path-state planes (87 GB at this size: batches are sized for 288 GB of HBM — longer queue
+segments drain the traversal's ray pools less often: 128 / 192 / 256 spp per batch measure 8179 / 8258 / 8430 Mray/s,
+profiles/README.md) and the film resident in HBM before the timed region starts. 1024 spp is 4 such steps, the default K.
 
 Metric (stats.rs:150-152): Mray/s = (closest_hit + shadow_rays) / render seconds / 1e6, summed
 over all ranks; the timed region is K steps bracketed by barrier + synchronize, MAX over ranks.
@@ -42,9 +42,9 @@ VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2  # wave64 VALU instructions/s: 256 CUs x 4
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp-per-step", type=int, default=128)
+    ap.add_argument("--spp-per-step", type=int, default=256)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default="cornellbox")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Writes profiles/r02_pmc_bench.json — what bench.py reports as roofline.traffic / hbm_measured_frac / l2_hit /
 valu_issue_frac — from PMC passes collected with profiles/run_pmc_r02.sh:
-    python profiles/summarize_pmc_bench.py "<workload key>=<tag>" ...      e.g. "cornellbox 1920x1080 128spp=cb"
+    python profiles/summarize_pmc_bench.py "<workload key>=<tag>" ...      e.g. "cornellbox 1920x1080 256spp=cb"
 Each tag names gpurun_out/pmc_<tag>_<pass>/; the workload key is bench.py's (`<scene> <w>x<h> <spp per step>spp`).
 The kernel reported is the pipeline's dominant production kernel: k_path<...> when the run launched it more often than
 once (bench.py launches the OTHER pipeline for two untimed steps), else k_extend<false, ...> (the per-stage pipeline).

@@ -4,10 +4,10 @@ ones compared with the oracle.
 
 Two kinds of comparison per config, both bit-exact (tolerance 0):
   * full frame at a low sample count: image bits + all eight RayStats counters against `ora_render`;
-  * the bench's batch shape — 128 spp of every pixel in ONE wavefront batch (265.4 M paths at 1920x1080; config 5
+  * the bench's batch shape — 256 spp of every pixel in ONE wavefront batch (530.8 M paths at 1920x1080; config 5
     at 3840x2160: 64 spp, 530.8 M paths) — against `ora_render_pixels` on a seeded random subset of pixels (per-pixel
     independence, tracer.rs:543, :559-560, makes a subset exact). cornellbox, the bench workload itself, is
-    compared over the whole frame at 128 spp.
+    compared over the whole frame at 256 spp.
 """
 import os
 
@@ -19,7 +19,7 @@ import ora_world
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BATCH = 128  # bench.py --spp-per-step default
+BATCH = 256  # bench.py --spp-per-step default
 BATCH_4K = 64  # config 5 at 3840x2160: 530.8 M paths, 87 GB of path state per batch
 
 
@@ -46,8 +46,9 @@ def _render(crt, name, w, h, depth, spp, rank=0, world=1):
 
 
 def test_config2_cornellbox_1080p_depth32_one_bench_batch_whole_frame(crt):
-    """configs[1], the bench workload at the bench's step shape (128 spp of every pixel in ONE batch: 265.4 M paths,
-    44 GB of path state, 768 workgroup segments): every pixel and every counter against the oracle's full frame."""
+    """configs[1], the bench workload at the bench's step shape (256 spp of every pixel in ONE batch: 530.8 M paths,
+    87 GB of path state, 2048 workgroup segments, the per-stage pipeline with the four-workgroups-per-CU traversal kernels):
+    every pixel and every counter against the oracle's full frame."""
     w, h, depth = 1920, 1080, 32
     r, desc = _render(crt, "cornellbox", w, h, depth, BATCH)
     assert r.settings.max_depth == depth
@@ -57,7 +58,7 @@ def test_config2_cornellbox_1080p_depth32_one_bench_batch_whole_frame(crt):
     _counters_equal(st, ost, "cornellbox 1080p, one bench batch")
     bad = np.argwhere(img.view(np.uint32) != oimg.view(np.uint32))
     assert bad.shape[0] == 0, f"{bad.shape[0]} differing components, first {bad[:3]}"
-    # and a second batch continues the same film exactly as the oracle's 256-sample pixel loop does (subset)
+    # and a second batch continues the same film exactly as the oracle's 512-sample pixel loop does (subset)
     import torch
     r.render_samples(BATCH, BATCH)
     torch.cuda.synchronize()
@@ -113,8 +114,8 @@ def test_config4_veach_mis_1080p_depth8_eight_shards(crt):
     assert np.array_equal(img.reshape(h, w, 3).view(np.uint32), oimg.view(np.uint32))
     for f in total:
         assert total[f] == getattr(ost, f), f
-    # one shard at the bench's batch shape (weak scaling: 128 spp x 8 ranks per step), a subset of ITS pixels
-    r, _ = _render(crt, "veach_mis", w, h, None, BATCH * 8, rank=5, world=8)  # 1024 spp of 1/8 of the pixels
+    # one shard at the bench's batch shape (weak scaling: 256 spp x 8 ranks per step), a subset of ITS pixels
+    r, _ = _render(crt, "veach_mis", w, h, None, BATCH * 8, rank=5, world=8)  # 2048 spp of 1/8 of the pixels
     own = r.pixel_indices()
     pick = np.sort(np.random.default_rng(4).choice(own.size, 512, replace=False))
     opx, _ = ora_world.OracleRenderer(desc, crt.usda).render_pixels(own[pick], BATCH * 8, forward=1)
