@@ -984,13 +984,18 @@ struct Renderer {
   uint32_t *d_state = nullptr, *d_active = nullptr, *d_count = nullptr;
   uint32_t n_act = 0, min_spp = 2;
   float variance_threshold = 0.0f;
-  // Two pipelines, chosen per scene at creation (crt_renderer_new): FUSED — the whole path loop of a batch in one launch
-  // (k_path, three workgroups per CU) for instance-heavy scenes — and PER-STAGE with the WIDE traversal kernels (four
-  // workgroups per CU) for flat ones. CRT_FUSED / CRT_WIDE override (A/B, per-stage timing).
-  bool fused = true, wide = false;
+  // Two pipelines: FUSED — the whole path loop of a batch in one launch (k_path, three workgroups per CU) — and PER-STAGE
+  // with the WIDE traversal kernels (four workgroups per CU). The scene decides which one it prefers (crt_renderer_new:
+  // `wide`), the batch whether the per-stage form pays: its 2-3 launches per bounce cost ~0.8 ms per batch, worth it from
+  // `stage_min_paths` paths up. CRT_FUSED / CRT_WIDE / CRT_STAGE_MIN_PATHS override (A/B, per-stage timing, tests).
+  bool wide = false;       // the scene's preference (wide_split)
+  int force_fused = -1;    // CRT_FUSED: -1 unset
+  size_t stage_min_paths = (size_t)64 << 20;
+  bool fused = true;       // what the LAST batch ran (crt_renderer_pipeline)
+  int grid_fused = 768, grid_stage = 2048;
   CrtLight *d_lights = nullptr;
   uint32_t *d_pixels = nullptr;
-  int grid = 2048;
+  int grid = 768;          // of the last batch (= grid_fused until a per-stage batch runs); misc kernels use it too
   hipStream_t last_stream = nullptr;
   bool profile = false;
   struct Ev { hipEvent_t a, b; int cls; };
@@ -1031,11 +1036,13 @@ struct Renderer {
     if (n_samples <= cap_samples && blob) return CRT_OK;
     if (blob) { (void)hipFree(blob); blob = nullptr; }
     const size_t total = (size_t)P.n_pix * n_samples;
-    const size_t seg = ((total + (size_t)grid * kBlock - 1) / ((size_t)grid * kBlock)) * kBlock;  // slots per segment: whole chunks
-    const size_t cap = seg * grid;        // shadow queue and staging film: one slot per path
+    size_t cap = 0;  // shadow queue and staging film: one slot per path, segments of whole chunks — for either pipeline's grid
+    for (int g : {grid_fused, grid_stage}) {
+      const size_t seg = ((total + (size_t)g * kBlock - 1) / ((size_t)g * kBlock)) * kBlock;
+      cap = seg * g > cap ? seg * g : cap;
+    }
     const size_t bcap = cap * kBins;      // path and hit planes: one sub-segment per (workgroup, direction bin)
     if (total == 0 || bcap >= (size_t)0x7fffffff) return CRT_ERR_BAD_ARG;
-    P.seg_cap = (uint32_t)seg;
     const size_t p16 = (cap * 16 + 255) & ~size_t(255);
     const size_t b16 = (bcap * 16 + 255) & ~size_t(255), b4 = (bcap * 4 + 255) & ~size_t(255);
     const bool lit = P.n_lights > 0, motion = P.has_motion != 0;
@@ -1080,10 +1087,14 @@ struct Renderer {
     p.sample_begin = sample_begin;
     p.n_act = adaptive ? n_act : P.n_pix;
     p.active = (adaptive && n_act < P.n_pix) ? d_active : nullptr;
-    {  // segment size for THIS batch (buffers may be larger)
+    {  // pipeline and segment size for THIS batch (buffers may be larger)
       const size_t total = (size_t)p.n_act * n_samples;
+      fused = force_fused >= 0 ? force_fused != 0 : !(wide && total >= stage_min_paths);
+      if (d_tstats) fused = false;  // the stats build is the per-stage one
+      grid = fused ? grid_fused : grid_stage;
       p.seg_cap = (uint32_t)(((total + (size_t)grid * kBlock - 1) / ((size_t)grid * kBlock)) * kBlock);
     }
+    const bool wide = !fused && this->wide;  // per-stage launches take the scene's preferred traversal kernels
     // the film fold: plain sum, or with the luminance statistics and the stopping rule, then the new active list
     auto fold = [&]() -> int {
       if (!adaptive) {
@@ -1103,7 +1114,7 @@ struct Renderer {
       return CRT_OK;
     };
     const bool lit = P.n_lights > 0;  // the kernel instance; whether the strategy samples the lights is checked in shade
-    if (fused && !d_tstats) {  // one launch for the whole path loop (class 0 of the profile), then the film fold
+    if (fused) {  // one launch for the whole path loop (class 0 of the profile), then the film fold
       timed(0, st, [&] {
 #define CRT_PATH(M, L, I) \
   hipLaunchKernelGGL((k_path<M, L, I>), dim3(grid), dim3(kBlock), 0, st, p, S[0], S[1], H, Q, C, staging, sample_begin, n_samples)
@@ -1289,15 +1300,20 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
   // trip (profiles/README.md).
   r.wide = wide_split(P.scene);
   if (const char *e = getenv("CRT_WIDE")) r.wide = atoi(e) != 0;
-  r.fused = !r.wide;
-  if (const char *e = getenv("CRT_FUSED")) r.fused = atoi(e) != 0;
+  if (const char *e = getenv("CRT_FUSED")) r.force_fused = atoi(e) != 0 ? 1 : 0;
+  if (const char *e = getenv("CRT_STAGE_MIN_PATHS")) r.stage_min_paths = (size_t)strtoull(e, nullptr, 10);
   // Workgroups per CU = queue segments per CU. Fused: 3, what stays resident (LDS of the traversal engine), so every
   // segment is as long as it can be and a wave's ray pool drains only once per launch. Per-stage wide: 8, two rounds of
-  // the four resident workgroups (measured: 4 / 8 / 12 / 16 -> cornellbox 7480 / 7790 / 7500 / 7490 Mray/s).
-  int mult = r.fused ? 3 : (r.wide ? 8 : 3);
-  if (const char *e = getenv("CRT_GRID_MULT")) mult = atoi(e) > 0 ? atoi(e) : mult;  // tuning knob
-  if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) r.grid = prop.multiProcessorCount * mult;
-  if (r.grid > kMaxGrid) r.grid = kMaxGrid;
+  // the four resident workgroups (measured: 4 / 6 / 8 / 10 / 12 / 16 -> cornellbox 7480 / 7070 / 8180 / 7400 / 8010 /
+  // 7490 Mray/s: whole rounds).
+  int cus = 256;
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  int mult_fused = 3, mult_stage = r.wide ? 8 : 3;
+  if (const char *e = getenv("CRT_GRID_MULT")) { if (atoi(e) > 0) mult_fused = mult_stage = atoi(e); }  // tuning knob
+  r.grid_fused = cus * mult_fused > kMaxGrid ? kMaxGrid : cus * mult_fused;
+  r.grid_stage = cus * mult_stage > kMaxGrid ? kMaxGrid : cus * mult_stage;
+  r.fused = r.force_fused >= 0 ? r.force_fused != 0 : !r.wide;  // until the first batch: the scene's preference
+  r.grid = r.fused ? r.grid_fused : r.grid_stage;
   return R;
 }
 void crt_renderer_free(CrtRenderer *r) { delete r; }

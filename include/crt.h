@@ -268,10 +268,12 @@ int crt_render_stats(CrtRenderer *r, CrtRayStats *out);
  * executions that contained a vertex of the class and how many of their 64 lanes held one. out_* (both or neither):
  * the counts since the last read, which also clears them. lanes / (64 * waves) is the class's lane utilisation. */
 int crt_renderer_shade_class_stats(CrtRenderer *r, int enable, uint64_t out_waves[4], uint64_t out_lanes[4]);
-/* The launch pipeline this renderer chose for its scene: out[0] = 1 fused (one launch runs generate and every
- * bounce's extend, shade and shadow stage of a batch; instance-heavy and sphere-only scenes), 0 one launch per stage
- * and bounce; out[1] = 1 when the traversal kernels are the four-workgroups-per-CU instances (flat triangle scenes);
- * out[2] = workgroups (= queue segments) per launch. Environment CRT_FUSED / CRT_WIDE / CRT_GRID_MULT override. */
+/* The launch pipeline of the last batch rendered (before the first: the scene's preference): out[0] = 1 fused (one
+ * launch runs generate and every bounce's extend, shade and shadow stage of the batch), 0 one launch per stage and
+ * bounce; out[1] = 1 when the traversal kernels are the four-workgroups-per-CU instances; out[2] = workgroups (= queue
+ * segments) per launch. The renderer takes the per-stage form for batches of >= 64 Mi paths of small flat triangle
+ * scenes and the fused kernel otherwise (instance-heavy or sphere-only scenes, small batches). Environment CRT_FUSED /
+ * CRT_WIDE / CRT_STAGE_MIN_PATHS / CRT_GRID_MULT override. */
 int crt_renderer_pipeline(const CrtRenderer *r, uint32_t out[3]);
 /* Live HIP-event timing of the kernels launched by crt_render_samples since the last reset, by class:
  * 0 = extend (closest-hit traversal) — or, in the fused pipeline, the path-loop kernel that runs generate, extend,

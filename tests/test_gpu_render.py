@@ -166,31 +166,36 @@ def test_tile_shards_reassemble_the_single_gpu_image(crt):
 @pytest.mark.parametrize("scene,w,h,depth", [("openpbr_showcase", 96, 54, 12), ("cornellbox", 96, 54, 8),
                                              ("nested_instancing", 64, 36, 6)])
 def test_the_three_pipelines_agree(crt, tmp_path, scene, w, h, depth):
-    """The renderer picks its pipeline per scene (pathtrace.hip, Renderer::fused): the fused path-loop kernel on three
-    workgroups per CU for instance-heavy scenes, one launch per stage with the four-workgroups-per-CU traversal kernels
-    for flat ones. All three combinations (fused; per-stage with either engine split) are the same device functions:
-    identical image and counters on a lit scene with interior media, a triangle scene and nested instances."""
+    """The renderer picks its pipeline per scene and batch (pathtrace.hip, Renderer::fused): the fused path-loop kernel on
+    three workgroups per CU, or one launch per stage with the four-workgroups-per-CU traversal kernels for large batches of
+    small flat triangle scenes. All combinations (fused; per-stage with either engine split; switching between batches of
+    one render) are the same device functions: identical image and counters on a lit scene with interior media, a
+    triangle scene and nested instances."""
     import subprocess
     import sys
     code = (
         "import os, sys, numpy as np; sys.path.insert(0, %r); import torch\n"
         "from __graft_entry__ import load_package; crt = load_package()\n"
         "r, _ = crt.load_usda(os.path.join(%r, 'scenes', %r + '.usda'), %d, %d, %d)\n"
-        "r.render_samples(0, 8); torch.cuda.synchronize(); st = r.stats()\n"
-        "np.save(sys.argv[1], r.image()); print(st.closest_hit, st.shadow_rays, st.vertices, st.rr_killed)\n"
+        "r.render_samples(0, 5); p1 = r.pipeline(); r.render_samples(5, 3); p2 = r.pipeline(); torch.cuda.synchronize(); st = r.stats()\n"
+        "np.save(sys.argv[1], r.image()); print(st.closest_hit, st.shadow_rays, st.vertices, st.rr_killed, int(p1['fused']), int(p1['wide']), int(p2['fused']))\n"
         % (ROOT, ROOT, scene, w, h, depth))
     outs = []
-    for tag, env in (("fused", dict(CRT_FUSED="1")), ("stage3", dict(CRT_FUSED="0", CRT_WIDE="0")),
-                     ("stage4", dict(CRT_FUSED="0", CRT_WIDE="1"))):
+    for tag, env, want in (("fused", dict(CRT_FUSED="1"), (1, 0, 1)), ("stage3", dict(CRT_FUSED="0", CRT_WIDE="0"), (0, 0, 0)),
+                           ("stage4", dict(CRT_FUSED="0", CRT_WIDE="1"), (0, 1, 0)),
+                           # the batch decides: 5 spp of every pixel reach the threshold, 3 do not
+                           ("by_batch", dict(CRT_WIDE="1", CRT_STAGE_MIN_PATHS=str(w * h * 4)), (0, 1, 1))):
         path = str(tmp_path / ("img_%s.npy" % tag))
         res = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True, text=True,
                              timeout=300)
         assert res.returncode == 0, (tag, res.stderr[-2000:])
-        outs.append((np.load(path), res.stdout.strip().splitlines()[-1]))
+        line = res.stdout.strip().splitlines()[-1].split()
+        assert tuple(int(x) for x in line[4:]) == want, (tag, line)
+        outs.append((np.load(path), line[:4]))
     for img, line in outs[1:]:
         assert line == outs[0][1]
         assert np.array_equal(img.view(np.uint32), outs[0][0].view(np.uint32))
-    assert int(outs[0][1].split()[0]) > w * h * 8  # bounces happened
+    assert int(outs[0][1][0]) > w * h * 8  # bounces happened
 
 
 def test_render_report_counts_the_scene_and_the_rays(crt, tmp_path):
