@@ -204,8 +204,9 @@ def main():
         # wave64 VALU instructions per second against the SIMDs' issue ceiling: CUs x 4 SIMD-32 x clock / 2 cycles
         valu_issue = round(pmc["valu_insts_per_launch"] / avg_s / (VALU_ISSUE_PEAK), 4)
         # where a wave's time goes (SQ_ACTIVE_INST_ANY, SQ_WAIT_ANY, SQ_WAIT_INST_ANY over SQ_WAVE_CYCLES)
-        wave = {"issuing": pmc.get("inst_active_frac"), "waiting_on_memory": pmc.get("wait_any_frac"),
-                "waiting_for_instructions": pmc.get("wait_inst_frac")}
+        rnd = lambda x: None if x is None else round(x, 4)
+        wave = {"issuing": rnd(pmc.get("inst_active_frac")), "waiting_on_memory": rnd(pmc.get("wait_any_frac")),
+                "waiting_for_instructions": rnd(pmc.get("wait_inst_frac"))}
     waves = 4 if pipe["wide"] else 3
     roofline = {
         "kernel": "k_path (one launch per batch: generate + BVH4 traversal + shading + shadow per queue segment)" if fused
