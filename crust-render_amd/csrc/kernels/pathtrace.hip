@@ -965,7 +965,7 @@ struct Renderer {
   std::shared_ptr<Scene> scene;
   Params P{};
   std::vector<uint32_t> pixels;  // owned pixels (linear buffer index), tile order
-  uint32_t cap_samples = 0;      // samples per batch the buffers are sized for
+  size_t cap_slots = 0;          // path slots (segment capacity x segments) the buffers are sized for
   char *blob = nullptr;
   size_t blob_bytes = 0;
   PathSoA S[2]{};
@@ -992,7 +992,7 @@ struct Renderer {
   int force_fused = -1;    // CRT_FUSED: -1 unset
   size_t stage_min_paths = (size_t)64 << 20;
   bool fused = true;       // what the LAST batch ran (crt_renderer_pipeline)
-  int grid_fused = 768, grid_stage = 2048;
+  int grid_fused = 768, cus = 256, stage_mult = 8, stage_mult_forced = 0;
   CrtLight *d_lights = nullptr;
   uint32_t *d_pixels = nullptr;
   int grid = 768;          // of the last batch (= grid_fused until a per-stage batch runs); misc kernels use it too
@@ -1032,15 +1032,22 @@ struct Renderer {
     events.clear();
   }
 
-  int ensure_buffers(uint32_t n_samples) {
-    if (n_samples <= cap_samples && blob) return CRT_OK;
+  // Workgroups (= queue segments) of a per-stage batch of `total` paths. 8 per CU — two rounds of the four resident
+  // workgroups — doubled while a segment would hold more than 192 Ki paths: shade and generate like segments of
+  // 64-128 Ki paths (cornellbox 1080p, Mray/s: 128 spp x8 8179, x12 8011, x16 7490; 256 spp x8 8420, x16 8630, x32 8655),
+  // and only power-of-two multiples of the CU count deal the camera samples evenly (x6 7066, x10 7397, x12 8011, x20 8318).
+  int stage_grid(size_t total) const {
+    int mult = stage_mult;
+    if (!stage_mult_forced && wide)
+      while (mult < 64 && total / ((size_t)cus * mult) > ((size_t)192 << 10)) mult *= 2;
+    const int g = cus * mult;
+    return g > kMaxGrid ? kMaxGrid : g;
+  }
+
+  int ensure_buffers(size_t slots) {  // slots = segment capacity x segments of the batch about to run
+    if (slots <= cap_slots && blob) return CRT_OK;
     if (blob) { (void)hipFree(blob); blob = nullptr; }
-    const size_t total = (size_t)P.n_pix * n_samples;
-    size_t cap = 0;  // shadow queue and staging film: one slot per path, segments of whole chunks — for either pipeline's grid
-    for (int g : {grid_fused, grid_stage}) {
-      const size_t seg = ((total + (size_t)g * kBlock - 1) / ((size_t)g * kBlock)) * kBlock;
-      cap = seg * g > cap ? seg * g : cap;
-    }
+    const size_t total = slots, cap = slots;  // shadow queue and staging film: one slot per path
     const size_t bcap = cap * kBins;      // path and hit planes: one sub-segment per (workgroup, direction bin)
     if (total == 0 || bcap >= (size_t)0x7fffffff) return CRT_ERR_BAD_ARG;
     const size_t p16 = (cap * 16 + 255) & ~size_t(255);
@@ -1060,7 +1067,7 @@ struct Renderer {
     H.h = (float4 *)take(b16); H.geom = (uint32_t *)take(b4);
     if (lit) { Q.a = (float4 *)take(p16); Q.b = (float4 *)take(p16); Q.c = (float4 *)take(p16); }
     staging = (float4 *)take(p16);
-    cap_samples = n_samples;
+    cap_slots = cap;
     return CRT_OK;
   }
 
@@ -1078,8 +1085,6 @@ struct Renderer {
   int render(uint32_t sample_begin, uint32_t n_samples, hipStream_t st, CrtTravStats *d_tstats) {
     if (n_samples == 0) return CRT_OK;
     if (n_samples > 0xffffu) return CRT_ERR_BAD_ARG;
-    int rc = ensure_buffers(n_samples);
-    if (rc != CRT_OK) return rc;
     last_stream = st;
     const bool adaptive = variance_threshold > 0.0f;
     if (adaptive && n_act == 0) return CRT_OK;  // every pixel has stopped
@@ -1087,12 +1092,14 @@ struct Renderer {
     p.sample_begin = sample_begin;
     p.n_act = adaptive ? n_act : P.n_pix;
     p.active = (adaptive && n_act < P.n_pix) ? d_active : nullptr;
-    {  // pipeline and segment size for THIS batch (buffers may be larger)
+    {  // pipeline, grid and segment size for THIS batch; the buffers grow when a batch needs more slots than any before
       const size_t total = (size_t)p.n_act * n_samples;
       fused = force_fused >= 0 ? force_fused != 0 : !(wide && total >= stage_min_paths);
       if (d_tstats) fused = false;  // the stats build is the per-stage one
-      grid = fused ? grid_fused : grid_stage;
+      grid = fused ? grid_fused : stage_grid(total);
       p.seg_cap = (uint32_t)(((total + (size_t)grid * kBlock - 1) / ((size_t)grid * kBlock)) * kBlock);
+      const int rc = ensure_buffers((size_t)p.seg_cap * grid);  // >= total: the staging film's (sample, active pixel) slots too
+      if (rc != CRT_OK) return rc;
     }
     const bool wide = !fused && this->wide;  // per-stage launches take the scene's preferred traversal kernels
     // the film fold: plain sum, or with the luminance statistics and the stopping rule, then the new active list
@@ -1303,17 +1310,14 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
   if (const char *e = getenv("CRT_FUSED")) r.force_fused = atoi(e) != 0 ? 1 : 0;
   if (const char *e = getenv("CRT_STAGE_MIN_PATHS")) r.stage_min_paths = (size_t)strtoull(e, nullptr, 10);
   // Workgroups per CU = queue segments per CU. Fused: 3, what stays resident (LDS of the traversal engine), so every
-  // segment is as long as it can be and a wave's ray pool drains only once per launch. Per-stage wide: 8, two rounds of
-  // the four resident workgroups (measured: 4 / 6 / 8 / 10 / 12 / 16 -> cornellbox 7480 / 7070 / 8180 / 7400 / 8010 /
-  // 7490 Mray/s: whole rounds).
-  int cus = 256;
-  if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-  int mult_fused = 3, mult_stage = r.wide ? 8 : 3;
-  if (const char *e = getenv("CRT_GRID_MULT")) { if (atoi(e) > 0) mult_fused = mult_stage = atoi(e); }  // tuning knob
-  r.grid_fused = cus * mult_fused > kMaxGrid ? kMaxGrid : cus * mult_fused;
-  r.grid_stage = cus * mult_stage > kMaxGrid ? kMaxGrid : cus * mult_stage;
+  // segment is as long as it can be and a wave's ray pool drains only once per launch. Per-stage: Renderer::stage_grid.
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) r.cus = prop.multiProcessorCount;
+  int mult_fused = 3;
+  r.stage_mult = r.wide ? 8 : 3;
+  if (const char *e = getenv("CRT_GRID_MULT")) { if (atoi(e) > 0) { mult_fused = r.stage_mult = atoi(e); r.stage_mult_forced = 1; } }  // tuning knob
+  r.grid_fused = r.cus * mult_fused > kMaxGrid ? kMaxGrid : r.cus * mult_fused;
   r.fused = r.force_fused >= 0 ? r.force_fused != 0 : !r.wide;  // until the first batch: the scene's preference
-  r.grid = r.fused ? r.grid_fused : r.grid_stage;
+  r.grid = r.fused ? r.grid_fused : r.stage_grid(0);
   return R;
 }
 void crt_renderer_free(CrtRenderer *r) { delete r; }
