@@ -47,7 +47,7 @@ def _render(crt, name, w, h, depth, spp, rank=0, world=1):
 
 def test_config2_cornellbox_1080p_depth32_one_bench_batch_whole_frame(crt):
     """configs[1], the bench workload at the bench's step shape (256 spp of every pixel in ONE batch: 530.8 M paths,
-    87 GB of path state, 2048 workgroup segments, the per-stage pipeline with the four-workgroups-per-CU traversal kernels):
+    87 GB of path state, 4096 workgroup segments, the per-stage pipeline with the four-workgroups-per-CU traversal kernels):
     every pixel and every counter against the oracle's full frame."""
     w, h, depth = 1920, 1080, 32
     r, desc = _render(crt, "cornellbox", w, h, depth, BATCH)
