@@ -305,8 +305,11 @@ inline uint8_t material_class(const CrtMaterial &m) {
   return 1;
 }
 
+// write_c: plane `c` of a camera path is a constant (throughput 1, radiance 0). The per-stage pipeline does not write
+// it here and does not read it in the first shade (17 GB less traffic per 531 M-path batch); the fused kernel keeps
+// the plain form — measured slower there with the special case (profiles/README.md, round 1).
 __device__ __forceinline__ void generate_segment(const Params &P, const PathSoA &S, Counters *C, uint32_t sample_begin,
-                                                 uint32_t n_samples, uint32_t *sobol_tab /* kSobolLdsWords */) {
+                                                 uint32_t n_samples, uint32_t *sobol_tab /* kSobolLdsWords */, bool write_c) {
   sobol_tables_init(sobol_tab);
   // Camera samples are dealt to the workgroup segments in round-robin chunks of one workgroup's width: slot k of
   // segment b holds global sample g = ((k / 256) * G + b) * 256 + k % 256. Every segment is then a uniform
@@ -342,7 +345,7 @@ __device__ __forceinline__ void generate_segment(const Params &P, const PathSoA 
     camera_get_ray(P.camera, u, v, cam[2], cam[3], o, d);
     st_nt(&S.a[i], make_float4(o.x, o.y, o.z, d.x));
     st_nt(&S.b[i], make_float4(d.y, d.z, 1.0f, 1.0f));
-    st_nt(&S.c[i], make_float4(1.0f, 0.0f, 0.0f, 0.0f));
+    if (write_c) st_nt(&S.c[i], make_float4(1.0f, 0.0f, 0.0f, 0.0f));
     st_nt(&S.d[i], make_uint4(new_domain(root, K_PATH).pattern /* tracer.rs:1101 */, pix, (P.max_depth & 0xffffu) << 16, sl));
     if (P.has_motion) st_nt(&S.time[i], time);
   }
@@ -364,7 +367,7 @@ __device__ __forceinline__ void generate_segment(const Params &P, const PathSoA 
 __global__ __launch_bounds__(kBlock) void k_generate(Params P, PathSoA S, Counters *C, uint32_t sample_begin,
                                                      uint32_t n_samples) {
   __shared__ uint32_t sobol_tab[kSobolLdsWords];
-  generate_segment(P, S, C, sample_begin, n_samples, sobol_tab);
+  generate_segment(P, S, C, sample_begin, n_samples, sobol_tab, false);
 }
 
 // ---- extend: World::intersect (rt_world.rs:207-232) for every live path ----
@@ -423,7 +426,8 @@ __global__ __launch_bounds__(kBlock, WIDE ? 4 : CRT_EXTEND_WAVES) void k_extend(
 template <int MATS, bool INF, bool LIT, int ARENA>
 __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S, const PathSoA &N, const HitSoA &H,
                                               const ShadowSoA &Q, Counters *C, int cur, float4 *staging,
-                                              uint32_t *sobol_tab /* ARENA dwords: Sobol tables, then the material table */) {
+                                              uint32_t *sobol_tab /* ARENA dwords: Sobol tables, then the material table */,
+                                              bool first /* camera paths whose plane c was not written (generate_segment) */) {
   constexpr bool MEDIA = MATS == 2, SIMPLE = MATS == 0;
   __shared__ uint32_t lds_ctr[10];  // [1] shadow requests, [2..8] statistics
   __shared__ uint32_t out_n[kBins];  // survivors per direction bin
@@ -500,7 +504,8 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
         const uint32_t hg = H.geom[i_c];
         // the escaped arm's operands are requested together with the classification's (one memory round trip, not
         // two); for a path that hit something they are loaded again by the vertex step, from L2
-        float4 A = S.a[i_c], B = S.b[i_c], Cc = S.c[i_c];
+        float4 A = S.a[i_c], B = S.b[i_c], Cc = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+        if (!first) Cc = S.c[i_c];
         asm volatile("" : "+v"(A.x), "+v"(B.x), "+v"(Cc.x));
         const int remaining = (int)(D.z >> 16);
         const bool carries_medium = MEDIA && (D.w >> kMediumShift) != 0;
@@ -558,7 +563,9 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
     uint32_t meta = 0, aux = 0, pix = 0, pattern = 0, n_med = 0;
     bool n_delta = false, n_prev_valid = true;
     if (active) {
-      const float4 A = S.a[i], B = S.b[i], Cc = S.c[i];
+      const float4 A = S.a[i], B = S.b[i];
+      float4 Cc = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+      if (!first) Cc = S.c[i];
       const uint4 D = S.d[i];
       const V3 ro = v3(A.x, A.y, A.z), rd = v3(A.w, B.x, B.y);
       time = P.has_motion ? S.time[i] : 0.0f;
@@ -790,10 +797,10 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
 }
 template <int MATS, bool INF, bool WIDE>
 __global__ __launch_bounds__(kBlock, WIDE ? 4 : CRT_SHADE_WAVES) void k_shade(Params P, PathSoA S, PathSoA N, HitSoA H, ShadowSoA Q,
-                                                                   Counters *C, int cur, float4 *staging) {
+                                                                   Counters *C, int cur, float4 *staging, int first) {
   constexpr int ARENA = WIDE ? kArenaWide : kArenaDwords;
   __shared__ uint32_t sobol_tab[ARENA];
-  shade_segment<MATS, INF, true, ARENA>(P, S, N, H, Q, C, cur, staging, sobol_tab);
+  shade_segment<MATS, INF, true, ARENA>(P, S, N, H, Q, C, cur, staging, sobol_tab, first != 0);
 }
 
 // ---- shadow: World::occluded (rt_world.rs:235-237) for the queue; unoccluded requests pay out ----
@@ -853,7 +860,7 @@ __global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_path(Params P, Pat
                                                  float4 *staging, uint32_t sample_begin, uint32_t n_samples) {
   __shared__ __attribute__((aligned(16))) uint32_t arena[kArenaDwords];
   __shared__ uint32_t live;
-  generate_segment(P, S0, C, sample_begin, n_samples, arena);
+  generate_segment(P, S0, C, sample_begin, n_samples, arena, true);
   __syncthreads();
   int cur = 0;
   for (uint32_t it = 0; it <= P.max_depth; it++) {
@@ -861,7 +868,7 @@ __global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_path(Params P, Pat
     const PathSoA &N = cur ? S0 : S1;
     extend_segment<false, false>(P, S, H, C, cur, it == 0 ? 1 : 0, nullptr, arena);
     __syncthreads();  // hit records of this segment are complete; the arena changes hands
-    shade_segment<MATS, INF, LIT, kArenaDwords>(P, S, N, H, Q, C, cur, staging, arena);
+    shade_segment<MATS, INF, LIT, kArenaDwords>(P, S, N, H, Q, C, cur, staging, arena, false);
     __syncthreads();
     if (LIT) {
       shadow_segment<false, false>(P, N, Q, C, staging, nullptr, arena);
@@ -1153,7 +1160,7 @@ struct Renderer {
       else { if (wide) CRT_EXTEND(false, true); else CRT_EXTEND(false, false); }
 #undef CRT_EXTEND
 #define CRT_SHADE(M, I, W) \
-  timed(1, st, [&] { hipLaunchKernelGGL((k_shade<M, I, W>), dim3(grid), dim3(kBlock), 0, st, p, S[cur], S[1 - cur], H, Q, C, cur, staging); })
+  timed(1, st, [&] { hipLaunchKernelGGL((k_shade<M, I, W>), dim3(grid), dim3(kBlock), 0, st, p, S[cur], S[1 - cur], H, Q, C, cur, staging, it == 0 ? 1 : 0); })
       if (mats_kind == 2) { if (P.has_inf_lights) CRT_SHADE(2, true, false); else CRT_SHADE(2, false, false); }
       else if (mats_kind == 1) { if (P.has_inf_lights) CRT_SHADE(1, true, false); else CRT_SHADE(1, false, false); }
       else if (P.has_inf_lights) CRT_SHADE(0, true, false);
