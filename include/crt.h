@@ -271,7 +271,7 @@ int crt_renderer_shade_class_stats(CrtRenderer *r, int enable, uint64_t out_wave
 /* The launch pipeline of the last batch rendered (before the first: the scene's preference): out[0] = 1 fused (one
  * launch runs generate and every bounce's extend, shade and shadow stage of the batch), 0 one launch per stage and
  * bounce; out[1] = 1 when the traversal kernels are the four-workgroups-per-CU instances; out[2] = workgroups (= queue
- * segments) per launch. The renderer takes the per-stage form for batches of >= 64 Mi paths of small flat triangle
+ * segments) per launch. The renderer takes the per-stage form for batches of >= 96 Mi paths of small flat triangle
  * scenes and the fused kernel otherwise (instance-heavy or sphere-only scenes, small batches). Environment CRT_FUSED /
  * CRT_WIDE / CRT_STAGE_MIN_PATHS / CRT_GRID_MULT override. */
 int crt_renderer_pipeline(const CrtRenderer *r, uint32_t out[3]);
