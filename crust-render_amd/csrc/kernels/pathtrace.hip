@@ -503,7 +503,8 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
         const uint4 D = S.d[i_c];
         const uint32_t hg = H.geom[i_c];
         // the escaped arm's operands are requested together with the classification's (one memory round trip, not
-        // two); for a path that hit something they are loaded again by the vertex step, from L2
+        // two); for a path that hit something they are loaded again by the vertex step, from L2. (Requested for the
+        // escaped lanes only — 48 B less per hit path — the per-stage shade is 1.5 % slower: profiles/README.md.)
         float4 A = S.a[i_c], B = S.b[i_c], Cc = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
         if (!first) Cc = S.c[i_c];
         asm volatile("" : "+v"(A.x), "+v"(B.x), "+v"(Cc.x));
@@ -795,12 +796,13 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
   if (threadIdx.x >= 1 && threadIdx.x <= 7 && lds_ctr[threadIdx.x + 1])
     atomicAdd(&C->stats[threadIdx.x], (unsigned long long)lds_ctr[threadIdx.x + 1]);
 }
-template <int MATS, bool INF, bool WIDE>
+template <int MATS, bool INF, bool WIDE, bool LIT>
 __global__ __launch_bounds__(kBlock, WIDE ? 4 : CRT_SHADE_WAVES) void k_shade(Params P, PathSoA S, PathSoA N, HitSoA H, ShadowSoA Q,
                                                                    Counters *C, int cur, float4 *staging, int first) {
+  static_assert(LIT || !INF, "lights at infinity are lights");
   constexpr int ARENA = WIDE ? kArenaWide : kArenaDwords;
   __shared__ uint32_t sobol_tab[ARENA];
-  shade_segment<MATS, INF, true, ARENA>(P, S, N, H, Q, C, cur, staging, sobol_tab, first != 0);
+  shade_segment<MATS, INF, LIT, ARENA>(P, S, N, H, Q, C, cur, staging, sobol_tab, first != 0);
 }
 
 // ---- shadow: World::occluded (rt_world.rs:235-237) for the queue; unoccluded requests pay out ----
@@ -1159,13 +1161,15 @@ struct Renderer {
       if (d_tstats) { if (wide) CRT_EXTEND(true, true); else CRT_EXTEND(true, false); }
       else { if (wide) CRT_EXTEND(false, true); else CRT_EXTEND(false, false); }
 #undef CRT_EXTEND
-#define CRT_SHADE(M, I, W) \
-  timed(1, st, [&] { hipLaunchKernelGGL((k_shade<M, I, W>), dim3(grid), dim3(kBlock), 0, st, p, S[cur], S[1 - cur], H, Q, C, cur, staging, it == 0 ? 1 : 0); })
-      if (mats_kind == 2) { if (P.has_inf_lights) CRT_SHADE(2, true, false); else CRT_SHADE(2, false, false); }
-      else if (mats_kind == 1) { if (P.has_inf_lights) CRT_SHADE(1, true, false); else CRT_SHADE(1, false, false); }
-      else if (P.has_inf_lights) CRT_SHADE(0, true, false);
-      else if (wide) CRT_SHADE(0, false, true);
-      else CRT_SHADE(0, false, false);
+#define CRT_SHADE(M, I, W, L) \
+  timed(1, st, [&] { hipLaunchKernelGGL((k_shade<M, I, W, L>), dim3(grid), dim3(kBlock), 0, st, p, S[cur], S[1 - cur], H, Q, C, cur, staging, it == 0 ? 1 : 0); })
+      // the instance: material table (MATS), lights at infinity (INF), four waves (simple materials without lights at
+      // infinity, when the scene runs the wide kernels), and — as for k_path — whether the light list is empty
+      if (mats_kind == 2) { if (P.has_inf_lights) CRT_SHADE(2, true, false, true); else if (lit) CRT_SHADE(2, false, false, true); else CRT_SHADE(2, false, false, false); }
+      else if (mats_kind == 1) { if (P.has_inf_lights) CRT_SHADE(1, true, false, true); else if (lit) CRT_SHADE(1, false, false, true); else CRT_SHADE(1, false, false, false); }
+      else if (P.has_inf_lights) CRT_SHADE(0, true, false, true);
+      else if (wide) { if (lit) CRT_SHADE(0, false, true, true); else CRT_SHADE(0, false, true, false); }
+      else { if (lit) CRT_SHADE(0, false, false, true); else CRT_SHADE(0, false, false, false); }
 #undef CRT_SHADE
       if (P.n_lights > 0 && P.strategy != CRT_STRATEGY_BSDF) {
 #define CRT_SHADOW(ST, W) \
