@@ -1001,10 +1001,10 @@ struct Renderer {
   int force_fused = -1;    // CRT_FUSED: -1 unset
   size_t stage_min_paths = (size_t)96 << 20;  // cornellbox 1080p, fused / per-stage Mray/s: 66 M paths 7507 / 7300, 133 M 7658 / 7900
   bool fused = true;       // what the LAST batch ran (crt_renderer_pipeline)
-  int grid_fused = 768, cus = 256, stage_mult = 8, stage_mult_forced = 0;
+  int cus = 256, fused_mult = 3, stage_mult = 8, mult_forced = 0;
   CrtLight *d_lights = nullptr;
   uint32_t *d_pixels = nullptr;
-  int grid = 768;          // of the last batch (= grid_fused until a per-stage batch runs); misc kernels use it too
+  int grid = 768;          // of the last batch; the film kernels use it too
   hipStream_t last_stream = nullptr;
   bool profile = false;
   struct Ev { hipEvent_t a, b; int cls; };
@@ -1041,13 +1041,16 @@ struct Renderer {
     events.clear();
   }
 
-  // Workgroups (= queue segments) of a per-stage batch of `total` paths. 8 per CU — two rounds of the four resident
-  // workgroups — doubled while a segment would hold more than 192 Ki paths: shade and generate like segments of
-  // 64-128 Ki paths (cornellbox 1080p, Mray/s: 128 spp x8 8179, x12 8011, x16 7490; 256 spp x8 8420, x16 8630, x32 8655),
-  // and only power-of-two multiples of the CU count deal the camera samples evenly (x6 7066, x10 7397, x12 8011, x20 8318).
-  int stage_grid(size_t total) const {
-    int mult = stage_mult;
-    if (!stage_mult_forced && wide)
+  // Workgroups (= queue segments) of a batch of `total` paths. Fused: 3 per CU, what stays resident (LDS of the
+  // traversal engine), so a wave's ray pool drains once per launch; per-stage: 8 — two rounds of the four resident
+  // workgroups. Either is doubled while a segment would hold more than 192 Ki paths: past that, shorter segments balance
+  // better than longer ones drain (per-stage, cornellbox 1080p, Mray/s: 128 spp x8 8179, x12 8011, x16 7490; 256 spp x8
+  // 8420, x16 8630, x32 8655 — fused, 531 M paths: MedCity x3 1985, x6 1997, x12 2028, x24 2041; openpbr_showcase 12077,
+  // 12142, 12179, 12067; 133 M paths: openpbr_showcase x3 11579, x6 11426, x12 11152). Only power-of-two multiples deal
+  // the camera samples evenly (per-stage x6 7066, x10 7397, x12 8011, x20 8318).
+  int batch_grid(size_t total, bool fused_pipeline) const {
+    int mult = fused_pipeline ? fused_mult : stage_mult;
+    if (!mult_forced && (fused_pipeline || wide))
       while (mult < 64 && total / ((size_t)cus * mult) > ((size_t)192 << 10)) mult *= 2;
     const int g = cus * mult;
     return g > kMaxGrid ? kMaxGrid : g;
@@ -1105,7 +1108,7 @@ struct Renderer {
       const size_t total = (size_t)p.n_act * n_samples;
       fused = force_fused >= 0 ? force_fused != 0 : !(wide && total >= stage_min_paths);
       if (d_tstats) fused = false;  // the stats build is the per-stage one
-      grid = fused ? grid_fused : stage_grid(total);
+      grid = batch_grid(total, fused);
       p.seg_cap = (uint32_t)(((total + (size_t)grid * kBlock - 1) / ((size_t)grid * kBlock)) * kBlock);
       const int rc = ensure_buffers((size_t)p.seg_cap * grid);  // >= total: the staging film's (sample, active pixel) slots too
       if (rc != CRT_OK) return rc;
@@ -1320,15 +1323,12 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
   if (const char *e = getenv("CRT_WIDE")) r.wide = atoi(e) != 0;
   if (const char *e = getenv("CRT_FUSED")) r.force_fused = atoi(e) != 0 ? 1 : 0;
   if (const char *e = getenv("CRT_STAGE_MIN_PATHS")) r.stage_min_paths = (size_t)strtoull(e, nullptr, 10);
-  // Workgroups per CU = queue segments per CU. Fused: 3, what stays resident (LDS of the traversal engine), so every
-  // segment is as long as it can be and a wave's ray pool drains only once per launch. Per-stage: Renderer::stage_grid.
+  // Workgroups per CU = queue segments per CU: Renderer::batch_grid.
   if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) r.cus = prop.multiProcessorCount;
-  int mult_fused = 3;
   r.stage_mult = r.wide ? 8 : 3;
-  if (const char *e = getenv("CRT_GRID_MULT")) { if (atoi(e) > 0) { mult_fused = r.stage_mult = atoi(e); r.stage_mult_forced = 1; } }  // tuning knob
-  r.grid_fused = r.cus * mult_fused > kMaxGrid ? kMaxGrid : r.cus * mult_fused;
+  if (const char *e = getenv("CRT_GRID_MULT")) { if (atoi(e) > 0) { r.fused_mult = r.stage_mult = atoi(e); r.mult_forced = 1; } }  // tuning knob
   r.fused = r.force_fused >= 0 ? r.force_fused != 0 : !r.wide;  // until the first batch: the scene's preference
-  r.grid = r.fused ? r.grid_fused : r.stage_grid(0);
+  r.grid = r.batch_grid(0, r.fused);
   return R;
 }
 void crt_renderer_free(CrtRenderer *r) { delete r; }
