@@ -160,7 +160,7 @@ ABI_SYMBOLS = [
     "crt_renderer_pixel_count", "crt_renderer_pixel_indices", "crt_render_samples", "crt_film_resolve",
     "crt_film_read", "crt_film_clear", "crt_renderer_active_pixels", "crt_renderer_sample_counts", "crt_render_stats", "crt_renderer_profile", "crt_renderer_profile_read",
     "crt_render_samples_stats", "crt_version", "crt_last_error", "crt_device_info",
-    "crt_scene_primitive_extents", "crt_scene_traversal_error", "crt_thread_release", "crt_renderer_shade_class_stats", "crt_renderer_pipeline",
+    "crt_scene_primitive_extents", "crt_scene_traversal_error", "crt_thread_release", "crt_renderer_shade_class_stats", "crt_renderer_pipeline", "crt_scene_image_check",
 ]
 
 _lib = None
@@ -210,6 +210,8 @@ def lib():
     L.crt_thread_release.restype = None
     L.crt_scene_unique_primitive_breakdown.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.crt_scene_memory_footprint.argtypes = [vp, C.POINTER(C.c_size_t)]
+    if hasattr(L, "crt_scene_image_check"):  # absent from older A/B variant libraries
+        L.crt_scene_image_check.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.crt_scene_tree.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                  C.POINTER(up)]
     L.crt_intersect1.argtypes = [vp, C.POINTER(CrtRay), C.c_float, C.c_float, C.POINTER(CrtRayHit)]
@@ -365,6 +367,14 @@ class Scene:
         out = (C.c_size_t * 5)()
         _check(lib().crt_scene_unique_primitive_breakdown(self.h, out), "crt_scene_unique_primitive_breakdown")
         return dict(zip(("triangles", "spheres", "curve_segments", "cubic_curve_spans", "instances"), map(int, out)))
+
+    def image_check(self):
+        """Host-only self-check of the device image (crt.h, crt_scene_image_check): counts, or CrtError naming the
+        broken invariant. Needs no GPU."""
+        out = (C.c_uint64 * 8)()
+        _check(lib().crt_scene_image_check(self.h, out), "crt_scene_image_check")
+        return dict(zip(("nodes", "leaf_words_plain", "leaf_words_direct_index", "leaf_words_direct_instance", "instances",
+                         "moving_instances", "staged_roots", "direct_leaves"), map(int, out)))
 
     def memory_footprint(self):
         out = (C.c_size_t * 6)()

@@ -213,6 +213,15 @@ int crt_scene_unique_primitive_breakdown(const CrtScene *s, size_t out[5]) {
   accumulate_unique(*s->p, visited, out);
   return CRT_OK;
 }
+int crt_scene_image_check(CrtScene *s, uint64_t out[8]) {
+  if (!s || !out) return CRT_ERR_BAD_ARG;
+  try {
+    return scene_image_check(*s->p, out);
+  } catch (const std::exception &e) {
+    set_error_text("crt_scene_image_check: %s", e.what());
+    return CRT_ERR_BAD_ARG;
+  }
+}
 int crt_scene_memory_footprint(CrtScene *s, size_t out[6]) {
   if (!s || !out) return CRT_ERR_BAD_ARG;
   int rc = s->p->ensure_device();

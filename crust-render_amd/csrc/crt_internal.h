@@ -211,6 +211,10 @@ struct Scene : std::enable_shared_from_this<Scene> {
   int ensure_device();               // CRT_OK or CRT_ERR_NO_DEVICE
 };
 
+// Host-only self-check of the image Scene::ensure_device would upload (scene.cpp): CRT_OK and eight counts, or
+// CRT_ERR_BAD_ARG with the broken invariant in crt_last_error.
+int scene_image_check(const Scene &scene, uint64_t out[8]);
+
 enum GeomKind { G_MESH, G_SPHERE, G_INSTANCE };
 struct Geom {
   GeomKind kind = G_MESH;

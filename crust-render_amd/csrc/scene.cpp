@@ -287,24 +287,34 @@ Flat::Placed place(Flat &f, const Scene &s) {
 }
 }  // namespace
 
-int Scene::ensure_device() {
-  std::lock_guard<std::mutex> lock(dev_mu);
-  if (dev) return CRT_OK;
-  if (!device_ok()) return CRT_ERR_NO_DEVICE;
+namespace {
+// The device image on the host: everything Scene::ensure_device uploads, plus what crt_scene_image_check verifies.
+struct FlatImage {
   Flat f;
-  Flat::Placed me = place(f, *this);
+  Flat::Placed me{CRT_INVALID_ID, 0};
+  uint32_t pool_stack = 6;
+  bool direct = false;
+  std::vector<uint32_t> leaf_of_word;  // per node lane (4 per node): the Leaf a leaf child word stands for, else ~0
+  uint32_t n_staged_roots = 0;
+};
+
+int flatten_image(const Scene &scene, FlatImage &im) {
+  Flat &f = im.f;
+  im.me = place(f, scene);
+  Flat::Placed &me = im.me;
   // kernels/traverse_pool.hip.h: the engine's LDS split. Deep stacks pay where rays spend their time inside
   // instances (thousands of placements); a handful of placements under a real top-level tree is still a flat scene.
   const bool many_instances = f.instances.size() >= 64;
   uint32_t pool_stack = many_instances ? 10u : 6u;
   if (const char *e = getenv("CRT_POOL_STACK_RT")) pool_stack = (uint32_t)atoi(e);  // A/B runs
+  im.pool_stack = pool_stack;
   const bool deep = pool_stack >= 10u;  // run_traversal's rule for the window size
-  // Renumber the nodes for the window the kernels stage in LDS (the first CRT_POOL_NODES / _DEEP nodes of the
-  // array): the top levels of the queried scene's tree breadth-first, then the ROOTS of the instanced trees, most
-  // placed first — every instance entry tests its tree's root (a city of 40 000 placements has 8 of them and a ray
-  // meets five per traversal), so they earn their slots before the third level of the top-level tree does — then
-  // the rest of the top-level tree and the instanced trees, breadth-first. Node numbers are opaque to traversal
-  // (children are visited by lane order and distance), so results and visit order do not change.
+  // Renumber the nodes for the window the kernels stage in LDS (the first nodes of the array; 72 / 16 / 26 of them
+  // by split): the queried scene's root, then the ROOTS of the instanced trees, most placed first — every instance
+  // entry tests its tree's root (a city of 40 000 placements has 8 of them and a ray meets five per traversal), so
+  // they earn their slots before the second level of the top-level tree does; at most half the smallest window the
+  // scene's kernels use — then the top-level tree and the instanced trees, breadth-first. Node numbers are opaque to
+  // traversal (children are visited by lane order and distance), so results and visit order do not change.
   if (!f.nodes.empty()) {
     std::vector<uint32_t> new_idx(f.nodes.size(), CRT_INVALID_ID), order;
     order.reserve(f.nodes.size());
@@ -313,13 +323,14 @@ int Scene::ensure_device() {
       new_idx[n] = uint32_t(order.size());
       order.push_back(n);
     };
-    auto bfs_from = [&](size_t head, size_t stop_at) {  // expands order[head ..) until `stop_at` nodes are numbered
-      while (head < order.size() && order.size() < stop_at) {
-        const WideNode &n = f.nodes[order[head++]];
+    auto bfs_tree = [&](uint32_t root) {  // numbers the tree under `root` breadth-first (root first, if it is new)
+      number(root);
+      std::vector<uint32_t> q{root};
+      for (size_t h = 0; h < q.size(); h++) {
+        const WideNode &n = f.nodes[q[h]];
         for (int l = 0; l < 4; l++)
-          if ((n.flags & (1u << l)) && !(n.flags & (1u << (4 + l)))) number(n.child[l]);
+          if ((n.flags & (1u << l)) && !(n.flags & (1u << (4 + l)))) { number(n.child[l]); q.push_back(n.child[l]); }
       }
-      return head;
     };
     std::vector<std::pair<uint32_t, uint32_t>> inner_roots;  // (placements, root), distinct
     {
@@ -331,21 +342,14 @@ int Scene::ensure_device() {
         return a.first != b.first ? a.first > b.first : a.second < b.second;
       });
     }
-    const size_t window = deep ? CRT_POOL_NODES_DEEP : CRT_POOL_NODES;
+    const size_t window = deep ? CRT_POOL_NODES_DEEP : std::min<size_t>(CRT_POOL_NODES, CRT_POOL_NODES_WIDE);
     size_t n_staged_roots = std::min(inner_roots.size(), window / 2);
     if (const char *e = getenv("CRT_STAGE_ROOTS")) n_staged_roots = std::min(n_staged_roots, (size_t)atoi(e));  // A/B runs
-    size_t head = 0;
-    if (me.root != CRT_INVALID_ID) {
-      number(me.root);
-      head = bfs_from(0, window - n_staged_roots);
-    }
+    im.n_staged_roots = uint32_t(n_staged_roots);
+    if (me.root != CRT_INVALID_ID) number(me.root);
     for (size_t k = 0; k < n_staged_roots; k++) number(inner_roots[k].second);
-    // the rest: nodes numbered but not yet expanded are expanded in numbering order, tree after tree
-    head = bfs_from(head, f.nodes.size() + 1);
-    for (const auto &r : inner_roots) {
-      number(r.second);
-      head = bfs_from(head, f.nodes.size() + 1);
-    }
+    if (me.root != CRT_INVALID_ID) bfs_tree(me.root);
+    for (const auto &r : inner_roots) bfs_tree(r.second);
     std::vector<WideNode> renum(order.size());
     for (size_t k = 0; k < order.size(); k++) {
       WideNode n = f.nodes[order[k]];
@@ -369,12 +373,16 @@ int Scene::ensure_device() {
   bool direct = many_instances || f.packets.empty();
   if (const char *e = getenv("CRT_DIRECT_LEAVES")) direct = atoi(e) != 0;  // A/B runs
   if (!CRT_DIRECT_LEAVES) direct = false;  // an engine built without the direct form must never meet one
+  im.direct = direct;
   bool direct_inst = CRT_DIRECT_INST != 0;
   if (const char *e = getenv("CRT_DIRECT_INST")) direct_inst = direct_inst && atoi(e) != 0;  // A/B runs
-  for (WideNode &n : f.nodes)
+  im.leaf_of_word.assign(f.nodes.size() * 4, CRT_INVALID_ID);
+  for (size_t ni = 0; ni < f.nodes.size(); ni++) {
+    WideNode &n = f.nodes[ni];
     for (int l = 0; l < 4; l++) {
       if (!(n.flags & (1u << l))) n.child[l] = CRT_INVALID_ID;
       else if (n.flags & (1u << (4 + l))) {
+        im.leaf_of_word[ni * 4 + l] = n.child[l];
         const Leaf &lf = f.leaves[n.child[l]];
         if (direct && lf.pkt_count == 0 && lf.idx_count >= 1 && lf.idx_count <= 3) {
           // instances in consecutive slots (what place() makes of a leaf of instances): the word names the first slot
@@ -393,7 +401,7 @@ int Scene::ensure_device() {
         n.child[l] |= 0x80000000u;
       }
     }
-  auto img = std::make_unique<DeviceImage>();
+  }
   // placements of the moving instances: behind the shading normals, addressed through the instance's flags word
   for (const auto &mv : f.moving) {
     const size_t at = (f.normals.size() + 3) & ~size_t(3);  // 16-byte aligned
@@ -405,6 +413,99 @@ int Scene::ensure_device() {
     std::memcpy(&f.normals[at], &mv.second, sizeof(DevInstanceMotion));
     f.instances[mv.first].flags |= uint32_t(at) << 2;
   }
+  return CRT_OK;
+}
+}  // namespace
+
+// Host-only self-check of the image (no device needed; tests/test_build_parity.py): every child word decodes to exactly
+// the node, leaf, scalar list or instance slots it stands for, the numbering is a permutation with the instanced roots
+// where the kernels' LDS window expects them, every record index is in range. out: nodes, leaf words in plain / direct
+// index / direct instance form, instance records, moving instances, instanced roots staged, 1 if direct leaves are on.
+int scene_image_check(const Scene &scene, uint64_t out[8]) {
+  FlatImage im;
+  int rc = flatten_image(scene, im);
+  if (rc != CRT_OK) return rc;
+  const Flat &f = im.f;
+  auto fail = [&](const char *what, size_t a, size_t b) {
+    set_error_text("scene image check: %s (%zu, %zu)", what, a, b);
+    return CRT_ERR_BAD_ARG;
+  };
+  uint64_t n_plain = 0, n_dindex = 0, n_dinst = 0;
+  std::vector<uint32_t> parents(f.nodes.size(), 0), leaf_refs(f.leaves.size(), 0);
+  for (size_t ni = 0; ni < f.nodes.size(); ni++)
+    for (int l = 0; l < 4; l++) {
+      const uint32_t w = f.nodes[ni].child[l], lo = im.leaf_of_word[ni * 4 + l];
+      const bool valid = (f.nodes[ni].flags >> l) & 1u, leaf = (f.nodes[ni].flags >> (4 + l)) & 1u;
+      if (!valid) { if (w != CRT_INVALID_ID) return fail("an empty lane is not the empty word", ni, l); continue; }
+      if (!leaf) {
+        if ((w & 0x80000000u) || w >= f.nodes.size()) return fail("inner child out of range", ni, w);
+        parents[w]++;
+        continue;
+      }
+      if (lo >= f.leaves.size() || !(w & 0x80000000u) || w == CRT_INVALID_ID) return fail("leaf word without its leaf", ni, l);
+      leaf_refs[lo]++;
+      const Leaf &lf = f.leaves[lo];
+      if (!(w & kDirectLeafTag)) {
+        if ((w & 0x7fffffffu) != lo) return fail("plain leaf word names another leaf", ni, lo);
+        n_plain++;
+        continue;
+      }
+      if (!im.direct || lf.pkt_count != 0) return fail("direct word for a leaf that has packets, or with direct leaves off", ni, lo);
+      const uint32_t count = (w >> 28) & 3u;
+      if (count != lf.idx_count || count == 0) return fail("direct word's count", count, lf.idx_count);
+      for (uint32_t k = 0; k < count; k++) {
+        const uint32_t want = f.indices[lf.idx_first + k];
+        const uint32_t got = (w & kDirectInstTag) ? (kIndexInstance | ((w & kDirectIndexMask) + k))
+                                                  : f.indices[(w & kDirectIndexMask) + k];
+        if (got != want) return fail("direct word's entries differ from the leaf's list", got, want);
+      }
+      (w & kDirectInstTag) ? n_dinst++ : n_dindex++;
+    }
+  for (size_t k = 0; k < f.leaves.size(); k++)
+    if (leaf_refs[k] != 1) return fail("a leaf is not referenced exactly once", k, leaf_refs[k]);
+  std::vector<uint8_t> is_root(f.nodes.size(), 0);
+  if (im.me.root != CRT_INVALID_ID) { if (im.me.root != 0) return fail("the queried scene's root is not node 0", im.me.root, 0); is_root[0] = 1; }
+  uint32_t staged = 0;
+  for (size_t k = 0; k < f.instances.size(); k++) {
+    const DevInstance &in = f.instances[k];
+    if (in.root == CRT_INVALID_ID) continue;
+    if (in.root >= f.nodes.size()) return fail("instance root out of range", k, in.root);
+    if (!is_root[in.root] && in.root >= 1 && in.root <= im.n_staged_roots) staged++;
+    is_root[in.root] = 1;
+  }
+  if (staged != im.n_staged_roots) return fail("instanced roots are not numbered right behind node 0", staged, im.n_staged_roots);
+  for (size_t k = 0; k < f.nodes.size(); k++)
+    if (parents[k] != (is_root[k] ? 0u : 1u)) return fail("node numbering is not a permutation of the trees", k, parents[k]);
+  for (uint32_t e : f.indices) {
+    if (e & kIndexInstance) { if ((e & ~kIndexInstance) >= f.instances.size()) return fail("list entry: instance slot", e, f.instances.size()); }
+    else if (e >= f.prims.size()) return fail("list entry: primitive", e, f.prims.size());
+  }
+  uint64_t moving = 0;
+  for (const auto &mv : f.moving) {
+    const DevInstance &in = f.instances[mv.first];
+    const size_t at = in.flags >> 2;
+    if (!(in.flags & 2u) || (at & 3u) || at + 24 > f.normals.size() ||
+        std::memcmp(&f.normals[at], &mv.second, sizeof(DevInstanceMotion)) != 0)
+      return fail("a moving instance's placements are not where its flags word says", mv.first, at);
+    moving++;
+  }
+  for (size_t k = 0; k < f.instances.size(); k++)
+    if (!(f.instances[k].flags & 2u) && (f.instances[k].flags >> 2) != 0) return fail("a static instance carries a placement offset", k, 0);
+  out[0] = f.nodes.size(); out[1] = n_plain; out[2] = n_dindex; out[3] = n_dinst;
+  out[4] = f.instances.size(); out[5] = moving; out[6] = im.n_staged_roots; out[7] = im.direct ? 1 : 0;
+  return CRT_OK;
+}
+
+int Scene::ensure_device() {
+  std::lock_guard<std::mutex> lock(dev_mu);
+  if (dev) return CRT_OK;
+  if (!device_ok()) return CRT_ERR_NO_DEVICE;
+  FlatImage im;
+  const int rc = flatten_image(*this, im);
+  if (rc != CRT_OK) return rc;
+  Flat &f = im.f;
+  const Flat::Placed me = im.me;
+  auto img = std::make_unique<DeviceImage>();
   constexpr int NA = 7;
   const size_t sz[NA] = {f.nodes.size() * sizeof(WideNode), f.leaves.size() * sizeof(Leaf),
                          f.packets.size() * sizeof(Tri4),   f.indices.size() * sizeof(uint32_t),
@@ -438,8 +539,8 @@ int Scene::ensure_device() {
   img->view.has_packets = me.has_packets;
   img->view.n_nodes = uint32_t(f.nodes.size());
   img->view.n_packets = uint32_t(f.packets.size());
-  img->view.direct_leaves = direct ? 1u : 0u;
-  img->view.pool_stack = pool_stack;
+  img->view.direct_leaves = im.direct ? 1u : 0u;
+  img->view.pool_stack = im.pool_stack;
   dev = std::move(img);
   return CRT_OK;
 }

@@ -126,6 +126,14 @@ int crt_scene_unique_primitive_breakdown(const CrtScene *s, size_t out[5]);
  * not cull" diagnostic over the top-level primitives' boxes. Any out pointer may be NULL.   scene.rs:446-455 */
 int crt_scene_primitive_extents(const CrtScene *s, size_t *count, float *scene_diagonal, float *mean_diagonal,
                                 float *max_diagonal);
+/* Host-only self-check of the device image this scene would upload — no GPU needed, nothing is uploaded: every child
+ * word of every node decodes to exactly the node, leaf, scalar list or instance slots it stands for (plain, direct and
+ * direct-instance forms), the node numbering is a permutation with the queried root at 0 and the instanced trees'
+ * roots right behind it, every record index is in range, a moving instance's placements sit where its flags word says.
+ * out: nodes | leaf words in plain / direct-index / direct-instance form | instance records | moving instances |
+ * instanced roots staged for the LDS window | 1 if direct leaves are on. CRT_ERR_BAD_ARG + crt_last_error on a broken
+ * invariant. (No reference counterpart: the image is this library's own layout of scene.rs:226-340's commit.) */
+int crt_scene_image_check(CrtScene *s, uint64_t out[8]);
 /* memory_footprint: prim_nodes, boxed_prims, bvh_nodes, leaves, packets, indices (device bytes) scene.rs:459 */
 int crt_scene_memory_footprint(CrtScene *s, size_t out[6]);
 /* Host copies of the committed tree of THIS scene (local indices), for build-parity checks:

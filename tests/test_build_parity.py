@@ -156,3 +156,63 @@ def test_large_builds_use_a_bounded_number_of_helper_threads(crt):
     a = ora.SceneBuilder()
     a.attach_triangles(verts, idx)
     _same_tree(a.commit(), s)
+
+
+# ---- the device image, checked on the host (crt_scene_image_check: no GPU, nothing uploaded) ----
+
+@pytest.mark.parametrize("name", list(scenes.ALL))
+def test_device_image_child_words_decode_to_their_leaves(crt, name):
+    """Every child word of the flattened image — plain, direct (bit 30: the scalar list itself) and direct-instance
+    (bit 27: consecutive instance slots) — decodes to exactly the node, leaf, list or slots it stands for; the node
+    numbering is a permutation with the queried root at 0 and the instanced roots right behind it (the kernels' LDS
+    window); every index is in range (crust-render_amd/csrc/scene.cpp, flatten_image)."""
+    make, _ = scenes.ALL[name]
+    st = make(crt).image_check()
+    assert st["nodes"] > 0
+    words = st["leaf_words_plain"] + st["leaf_words_direct_index"] + st["leaf_words_direct_instance"]
+    assert words > 0
+    if name == "instances":  # 125 placements of one prototype: instance-heavy -> direct leaves, every leaf a run of slots
+        assert st["direct_leaves"] == 1 and st["instances"] == 125 and st["staged_roots"] == 1
+        assert st["leaf_words_direct_instance"] > 0 and st["leaf_words_direct_index"] == 0
+    if name in ("sphere_grid",):  # no triangles at all: direct leaves, lists of primitive indices
+        assert st["direct_leaves"] == 1 and st["leaf_words_direct_index"] > 0 and st["leaf_words_direct_instance"] == 0
+    if name in ("tri_spheres", "shards"):  # triangle packets only: plain leaf words
+        assert st["direct_leaves"] == 0 and st["leaf_words_plain"] == words
+
+
+@pytest.mark.parametrize("seed", [3, 7, 13, 16, 18, 21])
+def test_device_image_of_random_scenes_is_consistent(crt, seed, monkeypatch):
+    """The same self-check over the fuzz recipes (nested and moving instances, spheres, masks), with the direct forms
+    forced on and off and both LDS splits: the encoder must be right for every combination the A/B knobs can reach."""
+    import fuzz_scenes
+    recipe = fuzz_scenes.recipe(seed)
+    for env in ({}, {"CRT_DIRECT_LEAVES": "1"}, {"CRT_DIRECT_LEAVES": "1", "CRT_DIRECT_INST": "0"}, {"CRT_DIRECT_LEAVES": "0"},
+                {"CRT_POOL_STACK_RT": "10", "CRT_DIRECT_LEAVES": "1"}, {"CRT_INST_ORDER": "0", "CRT_DIRECT_LEAVES": "1"}):
+        for k in ("CRT_DIRECT_LEAVES", "CRT_DIRECT_INST", "CRT_POOL_STACK_RT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            if k != "CRT_INST_ORDER":  # read once per process (static): left at its default here
+                monkeypatch.setenv(k, v)
+        scene, _protos = fuzz_scenes.build(crt, recipe)
+        st = scene.image_check()
+        assert st["direct_leaves"] == (0 if env.get("CRT_DIRECT_LEAVES") == "0" else st["direct_leaves"])
+        if env.get("CRT_DIRECT_INST") == "0":
+            assert st["leaf_words_direct_instance"] == 0
+        if env.get("CRT_DIRECT_LEAVES") == "0":
+            assert st["leaf_words_direct_index"] == 0 and st["leaf_words_direct_instance"] == 0
+
+
+def test_device_image_places_a_moving_instance_behind_the_normals(crt):
+    """A moving instance's two placements live in the normals array, addressed through its flags word (16-byte aligned,
+    behind the shading normals of smooth meshes); a static instance carries no offset."""
+    import fixtures as fx
+    inner = crt.SceneBuilder()
+    v, i = fx.uv_sphere((0, 0, 0), 1.0, 8, 4)
+    inner.attach_triangles(v, i, normals=v / np.linalg.norm(v, axis=1, keepdims=True))
+    inner = inner.commit()
+    b = crt.SceneBuilder()
+    b.attach_instance(inner, crt.affine(t=(0, 0, 0)))
+    b.attach_instance(inner, crt.affine(t=(3, 0, 0)), crt.affine(t=(3, 1, 0)))
+    b.attach_instance(inner, crt.affine(t=(6, 0, 0)), crt.affine(t=(6, 0, 2)))
+    st = b.commit().image_check()
+    assert st["instances"] == 3 and st["moving_instances"] == 2 and st["staged_roots"] == 1
