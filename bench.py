@@ -21,9 +21,11 @@ region), plus the 64-bit ray counters.
 
 roofline: for the dominant kernel of the pipeline the renderer chose for the scene — k_extend, the BVH4 closest-hit
 traversal, for flat triangle scenes (one launch per stage and bounce, four workgroups per CU); k_path, which runs a whole
-batch (generate, every bounce's traversal, shading and shadow stage) in one launch, for instance-heavy scenes:
-algorithmic bytes (SURVEY §8d formulas; traversal counters from the stats build of the same stages on the same batch)
-over the HIP-event duration of its launches in the timed region, against the 8 TB/s HBM peak. cpu_baseline: the
+batch (generate, every bounce's traversal, shading and shadow stage) in one launch, elsewhere: `achieved` = algorithmic
+bytes (SURVEY §8d formulas; traversal counters from the stats build of the same stages on the same batch) over the
+HIP-event duration of its launches in the timed region; `bound` / `peak` / `frac` name the memory tier that serves those
+bytes according to the committed PMC passes of this build (HBM when the measured fabric traffic reaches 30 % of its
+8 TB/s, else the L2 aggregate with bound "latency/issue"); the other stages' figures are under roofline.kernels. cpu_baseline: the
 oracle (CPU restatement, "port") rendering a bounded sample of the same workload on this box's host cores.
 """
 import argparse
@@ -92,9 +94,7 @@ def main():
     crt = load_package()
     crt.lib()
     # a sample scene file, or a labelled synthetic scene ("synthetic:city[:side]", crust-render_amd/synthetic.py)
-    path = args.scene if args.scene.startswith("synthetic:") else os.path.join(ROOT, "scenes", args.scene + ".usda")
-    if not args.scene.startswith("synthetic:") and not os.path.exists(path):
-        path = os.path.join(ROOT, "scenes", args.scene + ".usd")  # binary crate (PointInstancedMedCity)
+    path = crt.scene_path(args.scene)  # .usda text, .usd binary crate (PointInstancedMedCity), .usda.xz (stress)
     r, desc = crt.load_usda(path, args.width, args.height, args.depth, rank=rank, world=world)
     spp_step = args.spp_per_step * world
     stream = torch.cuda.current_stream()
@@ -105,6 +105,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # A part with less free HBM than the batch needs (the default shape holds 87 GB of path state) halves the batch until
+    # it fits; the shape actually run is what the line reports (config.spp_per_step).
+    requested = args.spp_per_step
+    while True:
+        try:
+            r.render_samples(0, spp_step, stream)
+            torch.cuda.synchronize()
+            break
+        except crt.CrtError:
+            if args.spp_per_step <= 1:
+                raise
+            args.spp_per_step //= 2
+            spp_step = args.spp_per_step * world
     sample = 0
     for _ in range(args.warmup):
         r.render_samples(sample, spp_step, stream)
@@ -150,24 +163,35 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel, N=1 figures of rank 0 ----
-    # The renderer picks its pipeline per scene (crt.h, crt_renderer_pipeline). FUSED (instance-heavy, sphere-only):
-    # ONE kernel per step, k_path — generate + every bounce's traversal, shading and shadow stage of a workgroup-private
-    # queue segment. PER-STAGE (flat triangle scenes: cornellbox, the default workload): one launch per stage and
-    # bounce; the dominant kernel is k_extend, the BVH4 closest-hit traversal, at four workgroups per CU.
-    # Algorithmic bytes per launch: the per-ray traversal formula summed over the rays the
-    # kernel traces in one batch (counters from the stats build of the same stages on the same batch) [+ fused: the
-    # shadow rays' and 352 B per shaded vertex: path state 96 B each way + 160 B material record], over its launches.
+    # ---- roofline, N=1 figures of rank 0 ----
+    # The renderer picks its pipeline per scene and batch (crt.h, crt_renderer_pipeline). FUSED: ONE kernel per step,
+    # k_path — generate + every bounce's traversal, shading and shadow stage of a workgroup-private queue segment.
+    # PER-STAGE: one launch per stage and bounce (k_extend / k_shade / k_shadow). Per kernel: ALGORITHMIC bytes per launch
+    # (the per-ray traversal formula summed over the rays the kernel traces in one batch —
+    # counters from the stats build of the same stages on the same batch shape — and 352 B per shaded vertex: path state
+    # 96 B each way + 160 B material record) over the HIP-event duration of its launches in the timed region.
     pipe = r.pipeline()
     fused = pipe["fused"]
     ext, sh = r.render_samples_stats(0, spp_step, stream)  # stats build, same batch shape; not timed
-    trav_bytes = ext.algorithmic_bytes() + sh.algorithmic_bytes()
-    shade_bytes = 352 * (st.vertices // max(args.steps, 1))
-    launch_bytes = (trav_bytes + shade_bytes) if fused else ext.algorithmic_bytes()
-    k_ms, k_n = prof["extend"]["ms"], prof["extend"]["launches"]   # class 0: k_path when fused, k_extend otherwise
-    per_launch = launch_bytes * args.steps / max(k_n, 1)
-    achieved = per_launch / (k_ms / max(k_n, 1) * 1e-3) / 1e9 if k_ms > 0 else 0.0
-    # the other pipeline on the same workload, 2 untimed steps: per-stage split of a fused step / the fused kernel's time
+    n_steps = max(args.steps, 1)
+    alg = {"extend": ext.algorithmic_bytes(), "shadow": sh.algorithmic_bytes(), "shade": 352 * (st.vertices // n_steps)}
+    if fused:
+        alg = {"extend": alg["extend"] + alg["shadow"] + alg["shade"]}  # class 0 of the profile is k_path
+    names = {"extend": "k_path" if fused else "k_extend", "shade": "k_shade", "shadow": "k_shadow"}
+    workload_key = "%s %dx%d %dspp" % (args.scene, args.width, args.height, spp_step)
+    waves = 4 if pipe["wide"] else 3
+    kernels = {}
+    for cls, per_step in alg.items():
+        k_ms, k_n = prof[cls]["ms"], prof[cls]["launches"]
+        if k_n == 0 or k_ms <= 0:
+            continue
+        kernels[names[cls]] = _roofline_entry(names[cls], per_step * n_steps / k_n, k_ms, k_n, n_steps, workload_key, world)
+    dominant = max(kernels, key=lambda k: kernels[k]["total_ms"]) if kernels else None
+    # the other pipeline on the same workload, 2 untimed steps: per-stage split of a fused step / the fused kernel's time.
+    # The timed renderer's buffers (87 GB at the default shape) are released first.
+    settings_depth = r.settings.max_depth
+    n_pix = r.n_pix
+    del r
     stage = other = None
     saved = {k: os.environ.get(k) for k in ("CRT_FUSED", "CRT_WIDE")}
     try:
@@ -175,72 +199,42 @@ def main():
         r2, _ = crt.load_usda(path, args.width, args.height, args.depth, rank=rank, world=world)
         r2.render_samples(0, spp_step, stream)
         torch.cuda.synchronize()
-        r2.profile(True)
-        for k in range(2):
-            r2.render_samples(k * spp_step, spp_step, stream)
-        torch.cuda.synchronize()
-        p2 = r2.profile_read()
-        if fused:
-            stage = {k: round(v["ms"] / 2, 3) for k, v in p2.items()}
-            stage["extend_algorithmic_gb_s"] = round(ext.algorithmic_bytes() / (p2["extend"]["ms"] / 2 * 1e-3) / 1e9, 1)
-        else:
-            other = {"fused_k_path_ms_per_step": round(p2["extend"]["ms"] / 2, 3), "other": round(p2["other"]["ms"] / 2, 3)}
+        if r2.pipeline()["fused"] != fused:  # scenes with lights at infinity have no fused form
+            r2.profile(True)
+            for k in range(2):
+                r2.render_samples(k * spp_step, spp_step, stream)
+            torch.cuda.synchronize()
+            p2 = r2.profile_read()
+            if fused:
+                stage = {k: round(v["ms"] / 2, 3) for k, v in p2.items()}
+                stage["extend_algorithmic_gb_s"] = round(ext.algorithmic_bytes() / (p2["extend"]["ms"] / 2 * 1e-3) / 1e9, 1)
+            else:
+                other = {"fused_k_path_ms_per_step": round(p2["extend"]["ms"] / 2, 3), "other": round(p2["other"]["ms"] / 2, 3)}
         del r2
+    except crt.CrtError as e:  # the probe is informational: a box with less free HBM still prints the line
+        other = {"error": str(e)}
     finally:
         for k, v in saved.items():
             if v is None:
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
-    # Measured counters of the same kernel, from the committed PMC passes IF they are of this build and workload.
-    workload_key = "%s %dx%d %dspp" % (args.scene, args.width, args.height, spp_step)
-    pmc, pmc_note = _pmc_for(workload_key, "k_path" if fused else "k_extend") if world == 1 else (None, "N > 1")
-    avg_s = (k_ms / max(k_n, 1)) * 1e-3
-    traffic = hbm_frac = l2_hit = valu_issue = wave = None
-    if pmc and avg_s > 0:
-        traffic = int(pmc["ea_dram_read_bytes_per_launch"] + pmc["ea_dram_write_bytes_per_launch"])
-        hbm_frac = round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4)
-        l2_hit = round(pmc["l2_hit_rate"], 4)
-        # wave64 VALU instructions per second against the SIMDs' issue ceiling: CUs x 4 SIMD-32 x clock / 2 cycles
-        valu_issue = round(pmc["valu_insts_per_launch"] / avg_s / (VALU_ISSUE_PEAK), 4)
-        # where a wave's time goes (SQ_ACTIVE_INST_ANY, SQ_WAIT_ANY, SQ_WAIT_INST_ANY over SQ_WAVE_CYCLES)
-        rnd = lambda x: None if x is None else round(x, 4)
-        wave = {"issuing": rnd(pmc.get("inst_active_frac")), "waiting_on_memory": rnd(pmc.get("wait_any_frac")),
-                "waiting_for_instructions": rnd(pmc.get("wait_inst_frac"))}
-    waves = 4 if pipe["wide"] else 3
-    roofline = {
-        "kernel": "k_path (one launch per batch: generate + BVH4 traversal + shading + shadow per queue segment)" if fused
-                  else "k_extend (BVH4 closest-hit traversal of one bounce's rays, %d workgroups per CU)" % waves,
+    roofline = dict(kernels[dominant]) if dominant else {}
+    roofline.update({
+        "kernel": {"k_path": "k_path (one launch per batch: generate + BVH4 traversal + shading + shadow per queue segment)",
+                   "k_extend": "k_extend (BVH4 closest-hit traversal of one bounce's rays, %d workgroups per CU)" % waves,
+                   "k_shade": "k_shade (one path vertex per live path: emission, NEE sample, OpenPBR sample, roulette, compaction)",
+                   "k_shadow": "k_shadow (BVH4 any-hit traversal of one bounce's shadow rays, %d workgroups per CU)" % waves}.get(dominant),
         "pipeline": "fused" if fused else ("per-stage, %d workgroups per CU in the traversal kernels" % waves),
-        # `achieved` / `frac` are the task's definition: ALGORITHMIC bytes over kernel time against the HBM
-        # peak. On this cache-resident scene most of those bytes never leave LDS / L1 / L2 — the physical picture is in
-        # the measured fields below: fabric-side traffic is a fraction of the peak, a wave spends its time half issuing
-        # instructions and half waiting on memory; the kernel is bound by latency and issue at its occupancy, not by HBM.
-        "bound": "hbm",
-        "achieved": round(achieved, 2),
-        "peak": HBM_PEAK_GBS,
-        "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 5),
-        "algorithmic_gb_s": round(achieved, 2),
-        "traffic": traffic,                    # measured L2<->fabric bytes per launch (TCC_EA0_*_DRAM_32B x 32 B), or null
-        "hbm_measured_frac": hbm_frac,         # traffic / launch time / 8 TB/s
-        "l2_hit": l2_hit,
-        "valu_issue_frac": valu_issue,
-        "wave_time": wave,
-        "physical_bound": ("dependent-load latency and per-wave instruction issue at %d waves/SIMD (see wave_time, "
-                           "hbm_measured_frac, valu_issue_frac)" % waves) if pmc else None,
-        "pmc_source": pmc_note,
         "kernel_source_hash": kernel_source_hash(),
-        "launches": k_n,
-        "launches_per_step": round(k_n / max(args.steps, 1), 2),
-        "avg_launch_ms": round(k_ms / max(k_n, 1), 5),
-        "bytes_per_launch": int(per_launch),
         "traversal_bytes_per_ray": round(ext.algorithmic_bytes() / max(int(ext.rays), 1), 1),
+        "shadow_bytes_per_ray": round(sh.algorithmic_bytes() / max(int(sh.rays), 1), 1) if int(sh.rays) else None,
         "shading_bytes_per_vertex": 352,
         "kernel_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
+        "kernels": {k: v for k, v in kernels.items() if k != dominant},  # the other stages of the per-stage pipeline
         "unfused_stage_ms_per_step": stage,
         "other_pipeline": other,
-    }
+    })
 
     cpu = None
     if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
@@ -264,9 +258,10 @@ def main():
         "config": {
             "workload": "%s %dx%d, %d spp per step per GPU-share (x%d GPUs), depth %d, triangle r=1, "
                         "variance 0; %d steps = %d spp" % (args.scene if args.scene.startswith("synthetic:") else "samples/" + os.path.basename(path), args.width, args.height, args.spp_per_step, world,
-                                                           r.settings.max_depth, args.steps, args.steps * spp_step),
+                                                           settings_depth, args.steps, args.steps * spp_step),
             "spp_per_step": spp_step,
-            "paths_per_step_per_gpu": r.n_pix * spp_step,
+            "spp_per_step_requested": requested * world,
+            "paths_per_step_per_gpu": n_pix * spp_step,
             "rays_total": total_rays,
             "closest_hit": rays[0],
             "shadow_rays": rays[1],
@@ -285,6 +280,55 @@ def main():
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md: L2 aggregate ~34.5 TB/s (eight XCDs x 4 MiB)
+
+
+def _roofline_entry(kernel, bytes_per_launch, k_ms, k_n, n_steps, workload_key, world):
+    """One kernel's roofline figures. `achieved` is the contract's definition — ALGORITHMIC bytes per launch over the
+    average launch duration (HIP events). `bound` / `peak` / `frac` name the tier that actually serves those bytes:
+    with the committed PMC passes of this build at hand (profiles/r03_pmc_bench.json, keyed by kernel source hash), a
+    kernel whose measured fabric traffic is below 30 % of the HBM peak is NOT HBM-bound — its bytes come out of L2 / L1 /
+    LDS and it is priced against the L2 aggregate (bound "latency/issue": see wave_time); otherwise against HBM. Without
+    PMC passes for this build the tier is decided from the algorithmic rate alone (more bytes per second than HBM can
+    deliver cannot be an HBM figure). The algorithmic rate against the HBM peak stays in hbm_frac_algorithmic."""
+    avg_s = k_ms / k_n * 1e-3
+    achieved = bytes_per_launch / avg_s / 1e9
+    pmc, note = _pmc_for(workload_key, kernel) if world == 1 else (None, "N > 1")
+    traffic = hbm_frac = l2_hit = valu_issue = wave = None
+    if pmc:
+        traffic = int(pmc["ea_dram_read_bytes_per_launch"] + pmc["ea_dram_write_bytes_per_launch"])
+        hbm_frac = round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4)
+        l2_hit = round(pmc["l2_hit_rate"], 4)
+        valu_issue = round(pmc["valu_insts_per_launch"] / avg_s / VALU_ISSUE_PEAK, 4)
+        rnd = lambda x: None if x is None else round(x, 4)
+        wave = {"issuing": rnd(pmc.get("inst_active_frac")), "waiting_on_memory": rnd(pmc.get("wait_any_frac")),
+                "waiting_for_instructions": rnd(pmc.get("wait_inst_frac"))}
+    hbm_bound = (hbm_frac >= 0.3) if hbm_frac is not None else (achieved <= HBM_PEAK_GBS * 0.9)
+    peak = HBM_PEAK_GBS if hbm_bound else L2_PEAK_GBS
+    return {
+        "bound": "hbm" if hbm_bound else "latency/issue",
+        "tier": "hbm" if hbm_bound else "l2",
+        "achieved": round(achieved, 2),
+        "peak": peak,
+        "unit": "GB/s",
+        "frac": round(achieved / peak, 5),
+        "algorithmic_gb_s": round(achieved, 2),
+        "hbm_frac_algorithmic": round(achieved / HBM_PEAK_GBS, 5),
+        "l2_frac": round(achieved / L2_PEAK_GBS, 5),
+        "traffic": traffic,                    # measured L2<->fabric bytes per launch (TCC_EA0_*_DRAM_32B x 32 B), or null
+        "hbm_measured_frac": hbm_frac,         # traffic / launch time / 8 TB/s
+        "l2_hit": l2_hit,
+        "valu_issue_frac": valu_issue,
+        "wave_time": wave,
+        "pmc_source": note,
+        "launches": k_n,
+        "launches_per_step": round(k_n / n_steps, 2),
+        "avg_launch_ms": round(k_ms / k_n, 5),
+        "total_ms": round(k_ms, 3),
+        "bytes_per_launch": int(bytes_per_launch),
+    }
 
 
 def _self_launch(n):
@@ -330,11 +374,11 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc_bench.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r03_pmc_bench.json")
 
 
 def _pmc_for(workload_key, kernel):
-    """The committed rocprofv3 --pmc passes for this workload and kernel (profiles/r02_pmc_bench.json, written by
+    """The committed rocprofv3 --pmc passes for this workload and kernel (profiles/r03_pmc_bench.json, written by
     profiles/summarize_pmc_bench.py) — but only if they were taken on THIS build: the file carries the kernel source
     hash of the build it profiled, and a profile of other sources says nothing about the kernel being timed now.
     Returns (entry or None, note)."""
@@ -348,12 +392,13 @@ def _pmc_for(workload_key, kernel):
     here = kernel_source_hash()
     if prof.get("kernel_source_hash") != here:
         return None, "PMC profile is of build %s, this build is %s: traffic not reported" % (prof.get("kernel_source_hash"), here)
-    e = prof.get("workloads", {}).get(workload_key)
-    if e is None:
+    w = prof.get("workloads", {}).get(workload_key)
+    if w is None:
         return None, "no PMC passes for workload %r" % workload_key
-    if not str(e.get("kernel", "")).startswith(kernel):
-        return None, "PMC passes for workload %r are of %s, the pipeline now runs %s" % (workload_key, e.get("kernel"), kernel)
-    return e, "profiles/r02_pmc_bench.json (git %s)" % prof.get("git_commit", "?")
+    e = w.get("kernels", {}).get(kernel)
+    if e is None:
+        return None, "PMC passes for workload %r hold %s, not %s" % (workload_key, sorted(w.get("kernels", {})), kernel)
+    return e, "%s (git %s)" % (os.path.relpath(PMC_PROFILE, ROOT), prof.get("git_commit", "?"))
 
 
 def _cpu_baseline(crt, desc, args):

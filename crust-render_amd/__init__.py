@@ -707,6 +707,18 @@ class Renderer:
         return {names[k]: dict(ms=float(ms[k]), launches=int(n[k])) for k in range(4)}
 
 
+def scene_path(name):
+    """scenes/<name> with the extension the file has: .usda (text), .usd (binary crate), .usda.xz (packed text)."""
+    import os
+    if str(name).startswith("synthetic:") or os.path.exists(name):
+        return name
+    base = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes", name)
+    for ext in (".usda", ".usd", ".usda.xz"):
+        if os.path.exists(base + ext):
+            return base + ext
+    raise FileNotFoundError("no scene %r under scenes/" % name)
+
+
 def load_usda(path, width=None, height=None, max_depth=None, rank=0, world=1, variance=0.0, min_spp=None):
     """Scene::from_usd (scene.rs / usd_import.rs:287-424) for the text sample scenes -> (Renderer, desc).
     `path` may also name a synthetic scene: "synthetic:city" or "synthetic:city:<side>" (synthetic.py).

@@ -670,8 +670,11 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
         } else if (!has_hit) {  // tracer.rs:1321-1342 (rays that carried a medium out of the scene end here)
           s_esc++;
           const V3 unit_direction = normalize(rd);
-          const V3 background = INF ? escaped_background(P.lights, n_lights, P.strategy, unit_direction,
-                                                        prev_valid && !prev_delta, S.e[i].w)
+          // plane e exists from the first bounce on (generate does not write it): a camera path never loads it
+          const bool competing = prev_valid && !prev_delta;
+          float prev_pdf = 0.0f;
+          if (INF && competing) prev_pdf = S.e[i].w;
+          const V3 background = INF ? escaped_background(P.lights, n_lights, P.strategy, unit_direction, competing, prev_pdf)
                                     : splat(0.0f) + sky_gradient(unit_direction);
           L = L + beta * background;
         } else {
@@ -857,7 +860,11 @@ __global__ __launch_bounds__(kBlock, WIDE ? 4 : CRT_SHADOW_WAVES) void k_shadow(
 // barrier separates the stages: no grid-wide barrier, no launch per bounce, and workgroups drift apart freely — while
 // one is shading (VALU-bound) its neighbours on the same SIMDs are traversing (latency-bound). A workgroup leaves as
 // soon as its segment is empty. LIT: the scene has lights and the strategy samples them (shadow stage present). ----
-template <int MATS, bool LIT, bool INF>
+// No instance for lights at infinity: those scenes (outside SURVEY §8) always run the per-stage launches. The one fault
+// this code base ever showed — round 2, run-to-run differences of a few ulps — was confined to k_path<., LIT, INF> of
+// one build, whose per-stage launches of the same shade code were exact; its cause was never established
+// (profiles/README.md, "The round-2 nondeterminism"), so that kernel family is not built.
+template <int MATS, bool LIT>
 __global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_path(Params P, PathSoA S0, PathSoA S1, HitSoA H, ShadowSoA Q, Counters *C,
                                                  float4 *staging, uint32_t sample_begin, uint32_t n_samples) {
   __shared__ __attribute__((aligned(16))) uint32_t arena[kArenaDwords];
@@ -870,7 +877,7 @@ __global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_path(Params P, Pat
     const PathSoA &N = cur ? S0 : S1;
     extend_segment<false, false>(P, S, H, C, cur, it == 0 ? 1 : 0, nullptr, arena);
     __syncthreads();  // hit records of this segment are complete; the arena changes hands
-    shade_segment<MATS, INF, LIT, kArenaDwords>(P, S, N, H, Q, C, cur, staging, arena, false);
+    shade_segment<MATS, false, LIT, kArenaDwords>(P, S, N, H, Q, C, cur, staging, arena, false);
     __syncthreads();
     if (LIT) {
       shadow_segment<false, false>(P, N, Q, C, staging, nullptr, arena);
@@ -1108,6 +1115,7 @@ struct Renderer {
       const size_t total = (size_t)p.n_act * n_samples;
       fused = force_fused >= 0 ? force_fused != 0 : !(wide && total >= stage_min_paths);
       if (d_tstats) fused = false;  // the stats build is the per-stage one
+      if (P.has_inf_lights) fused = false;  // no fused instance for lights at infinity (see k_path)
       grid = batch_grid(total, fused);
       p.seg_cap = (uint32_t)(((total + (size_t)grid * kBlock - 1) / ((size_t)grid * kBlock)) * kBlock);
       const int rc = ensure_buffers((size_t)p.seg_cap * grid);  // >= total: the staging film's (sample, active pixel) slots too
@@ -1135,22 +1143,15 @@ struct Renderer {
     const bool lit = P.n_lights > 0;  // the kernel instance; whether the strategy samples the lights is checked in shade
     if (fused) {  // one launch for the whole path loop (class 0 of the profile), then the film fold
       timed(0, st, [&] {
-#define CRT_PATH(M, L, I) \
-  hipLaunchKernelGGL((k_path<M, L, I>), dim3(grid), dim3(kBlock), 0, st, p, S[0], S[1], H, Q, C, staging, sample_begin, n_samples)
-        const int variant = mats_kind * 4 + (lit ? 2 : 0) + (P.has_inf_lights ? 1 : 0);
-        switch (variant) {
-          case 0: CRT_PATH(0, false, false); break;
-          case 1: CRT_PATH(0, false, true); break;
-          case 2: CRT_PATH(0, true, false); break;
-          case 3: CRT_PATH(0, true, true); break;
-          case 4: CRT_PATH(1, false, false); break;
-          case 5: CRT_PATH(1, false, true); break;
-          case 6: CRT_PATH(1, true, false); break;
-          case 7: CRT_PATH(1, true, true); break;
-          case 8: CRT_PATH(2, false, false); break;
-          case 9: CRT_PATH(2, false, true); break;
-          case 10: CRT_PATH(2, true, false); break;
-          default: CRT_PATH(2, true, true); break;
+#define CRT_PATH(M, L) \
+  hipLaunchKernelGGL((k_path<M, L>), dim3(grid), dim3(kBlock), 0, st, p, S[0], S[1], H, Q, C, staging, sample_begin, n_samples)
+        switch (mats_kind * 2 + (lit ? 1 : 0)) {
+          case 0: CRT_PATH(0, false); break;
+          case 1: CRT_PATH(0, true); break;
+          case 2: CRT_PATH(1, false); break;
+          case 3: CRT_PATH(1, true); break;
+          case 4: CRT_PATH(2, false); break;
+          default: CRT_PATH(2, true); break;
         }
 #undef CRT_PATH
       });

@@ -413,6 +413,24 @@ def _material_of(prim, by_path):
     if mat is None:
         return DEFAULT_MATERIAL
     shader = next((c for c in mat.children if c.type == "Shader"), None)
+    if shader is not None and shader.attr("info:id") == "UsdPreviewSurface":
+        # preview_surface_openpbr (usd_import.rs:2658-2700): OpenPBR::default() with the preview surface's AUTHORED inputs
+        # mapped onto it. (What openusd's read_preview_surface reports for unauthored inputs is not in this container;
+        # the one stage that uses this — scenes/stress.usda.xz — authors diffuseColor and roughness, and the spec's
+        # defaults for the rest equal OpenPBR's except clearcoatRoughness 0.01 against coat_roughness 0 at coat weight 0.)
+        out = {"_path": target}
+        for usd_name, field in (("diffuseColor", "base_color"), ("metallic", "base_metalness"), ("roughness", "specular_roughness"),
+                                ("opacity", "geometry_opacity"), ("ior", "specular_ior"), ("clearcoat", "coat_weight"),
+                                ("clearcoatRoughness", "coat_roughness")):
+            v = shader.attr("inputs:" + usd_name)
+            if v is not None:
+                out[field] = v
+        e = shader.attr("inputs:emissiveColor")
+        if e is not None:
+            out["emission_color"] = e
+            if max(float(x) for x in e) > 0.0:
+                out["emission_luminance"] = 1.0
+        return out
     if shader is None or shader.attr("info:id") != "crust:openpbr":
         return DEFAULT_MATERIAL  # no surface shader / unknown id -> default grey (usd_import.rs:2596-2631)
     out = {"_path": target}
@@ -470,6 +488,9 @@ def load(path, width=None, height=None):
     camera is built (the aspect ratio feeds Camera::new; the reference can only do this by editing the USD)."""
     with open(path, "rb") as f:
         raw = f.read()
+    if raw[:6] == b"\xfd7zXZ\x00":  # an .xz-compressed stage (scenes/stress.usda.xz: 15 MB of generated text, 0.7 MB packed)
+        import lzma
+        raw = lzma.decompress(raw)
     if raw[:8] == b"PXR-USDC":  # binary crate (SURVEY §8 f3): same Prim trees from the crate reader
         from . import usdc
         meta, roots = usdc.parse(raw)

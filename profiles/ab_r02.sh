@@ -10,7 +10,7 @@ run() { # tag, args...
   local lib=${v%%@*} envs=""
   if [ "$lib" != "$v" ]; then envs=$(echo "${v#*@}" | tr ',' ' '); fi   # name@VAR=1,VAR2=x : env settings for this variant
   if [ "$lib" = cur ]; then unset CRT_AMD_LIB; else export CRT_AMD_LIB=$PWD/variants/$lib.so; fi
-  env $envs timeout -k 10 240 python profiles/quick_bench.py --tag $v "$@" 2>/dev/null || echo "$v FAILED $*"
+  env $envs timeout -k 10 240 python profiles/quick_bench.py --tag $v "$@" 2>>gpurun_out/ab_stderr.log || { echo "$v FAILED $* (stderr kept in gpurun_out/ab_stderr.log); stopping: no further GPU step after a failed one"; tail -5 gpurun_out/ab_stderr.log; exit 1; }
 }
 for round in 1 2; do
   for v in $VARS; do

@@ -4,6 +4,6 @@ ARGS="$1"; shift
 for round in 1 2; do
   for v in "$@"; do
     if [ "$v" = cur ]; then unset CRT_AMD_LIB; else export CRT_AMD_LIB=$PWD/variants/$v.so; fi
-    timeout -k 10 200 python bench.py $ARGS --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['bytes_per_ray'])"
+    timeout -k 10 200 python bench.py $ARGS --no-cpu-baseline 2>>gpurun_out/ab_stderr.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['bytes_per_ray'])"
   done
 done

@@ -26,9 +26,7 @@ def main():
     import torch
     from __graft_entry__ import load_package
     crt = load_package()
-    path = a.scene if a.scene.startswith("synthetic:") else os.path.join(ROOT, "scenes", a.scene + ".usda")
-    if not a.scene.startswith("synthetic:") and not os.path.exists(path):
-        path = os.path.join(ROOT, "scenes", a.scene + ".usd")
+    path = crt.scene_path(a.scene)
     r, _ = crt.load_usda(path, a.width, a.height, a.depth)
     for k in range(a.warmup):
         r.render_samples(k * a.spp, a.spp)

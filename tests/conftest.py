@@ -40,3 +40,30 @@ def oracle():
     import ora
     ora.build()
     return ora
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """A failing GPU run keeps the code objects it failed on: the device objects (crust-render_amd/csrc/_obj/*.hip.o —
+    `llvm-objdump -d --offloading` gives the ISA back on any box) and the kernel source hash go to
+    gpurun_out/failed_build_<hash>/, which gpurun merges back. Round 2 lost the one build that rendered
+    nondeterministically because nothing of it was kept (profiles/README.md)."""
+    if exitstatus == 0 or not getattr(session, "testsfailed", 0):
+        return
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return
+        import shutil
+        sys.path.insert(0, ROOT)
+        from bench import kernel_source_hash
+        h = kernel_source_hash()
+        dst = os.path.join(ROOT, "gpurun_out", "failed_build_%s" % h)
+        os.makedirs(dst, exist_ok=True)
+        obj = os.path.join(ROOT, "crust-render_amd", "csrc", "_obj")
+        for n in os.listdir(obj) if os.path.isdir(obj) else []:
+            if n.endswith(".hip.o"):
+                shutil.copy2(os.path.join(obj, n), os.path.join(dst, n))
+        with open(os.path.join(dst, "README.txt"), "w") as f:
+            f.write("kernel source hash %s; %d test(s) failed; pytest args: %s\n" % (h, session.testsfailed, " ".join(session.config.invocation_params.args)))
+    except Exception as e:  # noqa: BLE001 — never mask the test result
+        print("could not keep the failing build's objects: %s" % e, file=sys.stderr)

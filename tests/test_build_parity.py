@@ -1,6 +1,7 @@
 """The product's host builder (C++, crust-render_amd/csrc/bvh_build.cpp) must emit the same tree as the
 oracle's independent restatement (plain C, oracle/ora_rt.c): node bounds, child links, flags, leaf ranges,
 packet lanes and index order, word for word. Runs on CPU (the builder is host code)."""
+import os
 import numpy as np
 import pytest
 
@@ -216,3 +217,27 @@ def test_device_image_places_a_moving_instance_behind_the_normals(crt):
     b.attach_instance(inner, crt.affine(t=(6, 0, 0)), crt.affine(t=(6, 0, 2)))
     st = b.commit().image_check()
     assert st["instances"] == 3 and st["moving_instances"] == 2 and st["staged_roots"] == 1
+
+
+@pytest.mark.parametrize("knobs", [{"CRT_DIRECT_LEAVES": "0"}, {"CRT_DIRECT_LEAVES": "0", "CRT_DIRECT_INST": "0"},
+                                   {"CRT_DIRECT_LEAVES": "1", "CRT_DIRECT_INST": "0"}])
+def test_instance_heavy_images_carry_no_direct_word_the_engine_was_told_not_to_read(crt, knobs, monkeypatch):
+    """The round-2 A/B abort (profiles/README.md, "The r02f abort"): an engine variant built WITHOUT the direct leaf form
+    met direct words the host had still written — on PointInstancedMedCity, the first instance-heavy scene of the run —
+    read a leaf index with bit 30 set, faulted, and took the box's GPU with it. The host now derives what it writes from
+    the same switches the engine is built with (scene.cpp: `if (!CRT_DIRECT_LEAVES) direct = false`, and the run-time
+    knobs of the same names); this checks the run-time half on the two instance-heavy images of the test set: no direct
+    word of a form that is switched off, and every word still decodes to its leaf."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    make, _ = scenes.ALL["instances"]  # 125 placements of one prototype
+    st = make(crt).image_check()
+    desc = crt.usda.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes", "PointInstancedMedCity.usd"), 64, 36)
+    scene, _mats, _protos = crt.usda.build_world(desc, crt, crt.default_material)
+    for s in (st, scene.image_check()):
+        assert s["instances"] >= 125
+        if knobs["CRT_DIRECT_LEAVES"] == "0":
+            assert s["direct_leaves"] == 0 and s["leaf_words_direct_index"] == 0 and s["leaf_words_direct_instance"] == 0
+            assert s["leaf_words_plain"] > 0
+        else:
+            assert s["direct_leaves"] == 1 and s["leaf_words_direct_instance"] == 0 and s["leaf_words_direct_index"] > 0

@@ -164,7 +164,7 @@ def test_tile_shards_reassemble_the_single_gpu_image(crt):
 
 
 @pytest.mark.parametrize("scene,w,h,depth", [("openpbr_showcase", 96, 54, 12), ("cornellbox", 96, 54, 8),
-                                             ("nested_instancing", 64, 36, 6)])
+                                             ("nested_instancing", 64, 36, 6), ("stress", 96, 54, 6)])
 def test_the_three_pipelines_agree(crt, tmp_path, scene, w, h, depth):
     """The renderer picks its pipeline per scene and batch (pathtrace.hip, Renderer::fused): the fused path-loop kernel on
     three workgroups per CU, or one launch per stage with the four-workgroups-per-CU traversal kernels for large batches of
@@ -176,10 +176,10 @@ def test_the_three_pipelines_agree(crt, tmp_path, scene, w, h, depth):
     code = (
         "import os, sys, numpy as np; sys.path.insert(0, %r); import torch\n"
         "from __graft_entry__ import load_package; crt = load_package()\n"
-        "r, _ = crt.load_usda(os.path.join(%r, 'scenes', %r + '.usda'), %d, %d, %d)\n"
+        "r, _ = crt.load_usda(crt.scene_path(%r), %d, %d, %d)\n"
         "r.render_samples(0, 5); p1 = r.pipeline(); r.render_samples(5, 3); p2 = r.pipeline(); torch.cuda.synchronize(); st = r.stats()\n"
         "np.save(sys.argv[1], r.image()); print(st.closest_hit, st.shadow_rays, st.vertices, st.rr_killed, int(p1['fused']), int(p1['wide']), int(p2['fused']))\n"
-        % (ROOT, ROOT, scene, w, h, depth))
+        % (ROOT, scene, w, h, depth))
     outs = []
     for tag, env, want in (("fused", dict(CRT_FUSED="1"), (1, 0, 1)), ("stage3", dict(CRT_FUSED="0", CRT_WIDE="0"), (0, 0, 0)),
                            ("stage4", dict(CRT_FUSED="0", CRT_WIDE="1"), (0, 1, 0)),
