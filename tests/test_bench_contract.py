@@ -96,19 +96,22 @@ def test_pmc_profile_is_reported_only_for_the_build_it_was_taken_on(tmp_path, mo
     assert e is None and "no PMC profile" in note
     entry = {"kernel": "k_extend<false, true>", "ea_dram_read_bytes_per_launch": 1.0, "ea_dram_write_bytes_per_launch": 2.0, "l2_hit_rate": 0.5,
              "valu_insts_per_launch": 3.0}
-    prof.write_text(json.dumps({"kernel_source_hash": "0" * 16, "workloads": {"cornellbox 1920x1080 64spp": entry}}))
+    wl = {"cornellbox 1920x1080 64spp": {"kernels": {"k_extend": entry}}}  # per workload, per kernel of the pipeline
+    prof.write_text(json.dumps({"kernel_source_hash": "0" * 16, "workloads": wl}))
     e, note = bench._pmc_for("cornellbox 1920x1080 64spp", "k_extend")
     assert e is None and "not reported" in note
-    prof.write_text(json.dumps({"kernel_source_hash": here, "git_commit": "abc", "workloads": {"cornellbox 1920x1080 64spp": entry}}))
+    prof.write_text(json.dumps({"kernel_source_hash": here, "git_commit": "abc", "workloads": wl}))
     e, note = bench._pmc_for("cornellbox 1920x1080 64spp", "k_extend")
     assert e == entry and "abc" in note
     assert bench._pmc_for("veach_mis 1920x1080 64spp", "k_extend")[0] is None    # another workload: nothing to report
     assert bench._pmc_for("cornellbox 1920x1080 64spp", "k_path")[0] is None     # the other pipeline's kernel: not what was profiled
     # the committed profile, if present, is well-formed
-    real = os.path.join(ROOT, "profiles", "r02_pmc_bench.json")
+    real = os.path.join(ROOT, "profiles", "r03_pmc_bench.json")
     if os.path.exists(real):
         d = json.load(open(real))
         assert len(d["kernel_source_hash"]) == 16 and d["workloads"]
         for w in d["workloads"].values():
-            for k in entry:
-                assert (w[k] > 0) if k != "kernel" else w[k].startswith(("k_path", "k_extend")), k
+            assert w["kernels"]
+            for base, e in w["kernels"].items():
+                for k in entry:
+                    assert (e[k] > 0) if k != "kernel" else e[k].startswith(base), (base, k)
