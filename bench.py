@@ -95,7 +95,8 @@ def main():
     crt.lib()
     # a sample scene file, or a labelled synthetic scene ("synthetic:city[:side]", crust-render_amd/synthetic.py)
     path = crt.scene_path(args.scene)  # .usda text, .usd binary crate (PointInstancedMedCity), .usda.xz (stress)
-    r, desc = crt.load_usda(path, args.width, args.height, args.depth, rank=rank, world=world)
+    # N > 1: rank 0 imports the file, the other ranks receive the description in one broadcast (shard.import_once)
+    r, desc = crt.load_usda(path, args.width, args.height, args.depth, rank=rank, world=world, dist=dist)
     spp_step = args.spp_per_step * world
     stream = torch.cuda.current_stream()
 
@@ -148,12 +149,13 @@ def main():
     prof = r.profile_read()
     r.profile(False)
 
-    rays = torch.tensor([st.closest_hit, st.shadow_rays, st.camera_rays, st.vertices], dtype=torch.int64, device=coll)
+    # the job's RayStats: all eight counters (stats.rs:128-147), one all_reduce
+    all_stats = crt.shard.reduce_ray_stats(st, dist, coll)
+    names = [f for f, _t in st._fields_]
+    rays = [all_stats[names.index(f)] for f in ("closest_hit", "shadow_rays", "camera_rays", "vertices")]
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll)
     if dist is not None:
-        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    rays = rays.cpu().tolist()
     elapsed = float(tmax.item())
     total_rays = rays[0] + rays[1]
     value = total_rays / elapsed / 1e6
@@ -267,6 +269,7 @@ def main():
             "shadow_rays": rays[1],
             "camera_rays": rays[2],
             "mean_path_length": round(rays[3] / max(rays[2], 1), 3),
+            "ray_stats": dict(zip(names, all_stats)),
             "seconds": round(elapsed, 4),
             "spp_per_second": round(args.steps * spp_step / elapsed, 2),
             # the second half of BASELINE's metric: wall clock to the configuration's target spp (configs[1]: 1024) at this rate
@@ -431,6 +434,7 @@ def _cpu_baseline(crt, desc, args):
         "value": round(st.total_rays() / dt / 1e6, 3),
         "unit": "Mray/s",
         "cores": cores,
+        "host_affinity": avail,  # hardware threads this process may run on; `cores` of them were used
         "kind": "port",
         "sample": "%dx%d full frame at %d spp (%d rays), best of %d runs (%s s), reference-order estimator, host: %s" % (
             args.width, args.height, args.cpu_spp, st.total_rays(), len(times), " / ".join("%.1f" % t for t in times), model),

@@ -719,12 +719,13 @@ def scene_path(name):
     raise FileNotFoundError("no scene %r under scenes/" % name)
 
 
-def load_usda(path, width=None, height=None, max_depth=None, rank=0, world=1, variance=0.0, min_spp=None):
+def load_usda(path, width=None, height=None, max_depth=None, rank=0, world=1, variance=0.0, min_spp=None, dist=None):
     """Scene::from_usd (scene.rs / usd_import.rs:287-424) for the text sample scenes -> (Renderer, desc).
     `path` may also name a synthetic scene: "synthetic:city" or "synthetic:city:<side>" (synthetic.py).
     variance > 0 enables adaptive stopping (the scene files' own default is 0.05; 0 = every sample, the rule for
-    comparable runs, scripts/check_images.sh:5-11)."""
-    from . import usda
+    comparable runs, scripts/check_images.sh:5-11). dist: the job's torch.distributed module — the file is then imported
+    by rank 0 only and broadcast (shard.import_once)."""
+    from . import usda, shard
     import sys
     if str(path).startswith("synthetic:"):
         from . import synthetic
@@ -732,7 +733,7 @@ def load_usda(path, width=None, height=None, max_depth=None, rank=0, world=1, va
         kw = dict(side=int(parts[2])) if len(parts) > 2 else {}
         desc = getattr(synthetic, parts[1])(width or 640, height or 360, **kw)
     else:
-        desc = usda.load(path, width, height)
+        desc = shard.import_once(path, width, height, dist)
     me = sys.modules[__name__]
     scene, materials, protos = usda.build_world(desc, me, default_material)
     s = desc.settings

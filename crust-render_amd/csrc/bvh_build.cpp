@@ -286,9 +286,10 @@ Subtree build_children(const std::vector<Prim> &prims, const Aabb &bbox, std::ve
       bool spawned = true;
       try {
         fut = std::async(std::launch::async, [&prims, &l, depth, root_area]() {
-          Subtree t = build_subtree(prims, std::move(l), depth + 1, root_area);
-          g_build_helpers.fetch_sub(1);
-          return t;
+          // the token goes back on every way out of the helper, an exception (bad_alloc -> crt_commit returns NULL)
+          // included: a failed commit must not shrink the pool for the rest of the process
+          struct TokenReturn { ~TokenReturn() { g_build_helpers.fetch_sub(1); } } token_return;
+          return build_subtree(prims, std::move(l), depth + 1, root_area);
         });
       } catch (const std::system_error &) {  // thread limit reached: nothing was moved from, build inline
         g_build_helpers.fetch_sub(1);

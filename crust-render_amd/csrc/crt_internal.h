@@ -154,7 +154,7 @@ struct DevScene {
   uint32_t n_nodes;      // numbered for the LDS window: top of the top-level tree, the instanced trees' roots, then
                          // the rest breadth-first (see Scene::ensure_device)
   uint32_t pool_stack;   // LDS stack entries per ray the traversal engine uses for this scene (6 flat, 10 instanced)
-  uint32_t n_packets;    // Tri4 packets, top-level tree first: the first ones are staged in LDS behind the node window
+  uint32_t n_packets;    // Tri4 packets, the queried tree's first (scene.cpp rotates them there; crt_scene_image_check): the first ones are staged in LDS behind the node window
   uint32_t direct_leaves;  // leaves without packets and with 1-3 scalar entries are encoded in the child word (below)
 };
 // Device child words of a node: inner child = node index; leaf child = kLeafTag | leaf index; empty lane =

@@ -259,21 +259,42 @@ __device__ __forceinline__ void add_stat(uint32_t *lds_slot, uint32_t v) {
 }
 
 // ---- interior media of the materials (openpbr.rs:225-258), derived once on the device so that the logarithms
-// are the same deterministic sequence the shading kernels use. One thread: ids are assigned in material order. ----
-__global__ void k_build_media(const CrtMaterial *materials, uint32_t n, DevMedium *media, DevMedium *by_id,
-                              uint32_t *count_out) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  uint32_t count = 0;
-  for (uint32_t i = 0; i < n; i++) {
-    DevMedium m;
-    medium_from_material(materials[i], m);
-    if (m.present) {
-      count++;
-      if (count <= kMaxMedia) { m.id = count; by_id[count - 1] = m; }
-    }
-    media[i] = m;
+// are the same deterministic sequence the shading kernels use. Two launches: every record in parallel (40 008 of them on
+// the instanced city: one thread looping took 31.6 ms), then ONE workgroup numbers the present ones in material order —
+// each thread counts a contiguous run of the table, an LDS prefix over the 1024 runs, ids handed out run by run. ----
+__global__ void k_build_media(const CrtMaterial *materials, uint32_t n, DevMedium *media) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  DevMedium m;
+  medium_from_material(materials[i], m);
+  m.id = 0;
+  media[i] = m;
+}
+constexpr int kNumberBlock = 1024;
+__global__ __launch_bounds__(kNumberBlock) void k_number_media(uint32_t n, DevMedium *media, DevMedium *by_id, uint32_t *count_out) {
+  __shared__ uint32_t run_sum[kNumberBlock];
+  const uint32_t per = (n + kNumberBlock - 1) / kNumberBlock;
+  const uint32_t lo = threadIdx.x * per < n ? threadIdx.x * per : n, hi = lo + per < n ? lo + per : n;
+  uint32_t mine = 0;
+  for (uint32_t i = lo; i < hi; i++) mine += media[i].present ? 1u : 0u;
+  run_sum[threadIdx.x] = mine;
+  __syncthreads();
+  for (int off = 1; off < kNumberBlock; off <<= 1) {  // inclusive Hillis-Steele prefix
+    const uint32_t add = (int)threadIdx.x >= off ? run_sum[threadIdx.x - off] : 0u;
+    __syncthreads();
+    run_sum[threadIdx.x] += add;
+    __syncthreads();
   }
-  *count_out = count;
+  uint32_t count = run_sum[threadIdx.x] - mine;  // present records before this run
+  for (uint32_t i = lo; i < hi; i++) {
+    if (!media[i].present) continue;
+    count++;
+    if (count <= kMaxMedia) {
+      media[i].id = count;
+      by_id[count - 1] = media[i];
+    }
+  }
+  if (threadIdx.x == kNumberBlock - 1) *count_out = run_sum[threadIdx.x];
 }
 
 // ---- generate: PathSampler::new(...).new_domain(tile), camera sample, camera ray (tracer.rs:559-585) ----
@@ -1295,7 +1316,9 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
     uint32_t *d_count = nullptr, h_count = 0;
     ok = CRT_HIP_OK(hipMalloc(&r.d_media, 2 * n_materials * sizeof(DevMedium))) && CRT_HIP_OK(hipMalloc(&d_count, 4));
     if (ok) {
-      hipLaunchKernelGGL(k_build_media, dim3(1), dim3(64), 0, nullptr, r.d_materials, (uint32_t)n_materials, r.d_media,
+      hipLaunchKernelGGL(k_build_media, dim3((unsigned)((n_materials + 255) / 256)), dim3(256), 0, nullptr, r.d_materials,
+                         (uint32_t)n_materials, r.d_media);
+      hipLaunchKernelGGL(k_number_media, dim3(1), dim3(kNumberBlock), 0, nullptr, (uint32_t)n_materials, r.d_media,
                          r.d_media + n_materials, d_count);
       ok = CRT_HIP_OK(hipGetLastError()) && CRT_HIP_OK(hipMemcpy(&h_count, d_count, 4, hipMemcpyDeviceToHost));
       ok = ok && h_count <= kMaxMedia;  // the path state carries a 14-bit medium id

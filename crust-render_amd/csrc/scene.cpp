@@ -296,12 +296,26 @@ struct FlatImage {
   bool direct = false;
   std::vector<uint32_t> leaf_of_word;  // per node lane (4 per node): the Leaf a leaf child word stands for, else ~0
   uint32_t n_staged_roots = 0;
+  uint32_t n_top_packets = 0;  // the queried scene's own Tri4 packets: the first ones of the array
 };
 
 int flatten_image(const Scene &scene, FlatImage &im) {
   Flat &f = im.f;
   im.me = place(f, scene);
   Flat::Placed &me = im.me;
+  // place() appends a scene BEHIND everything it instances, so the queried scene's packets arrive last. The kernels
+  // stage the FIRST packets of the array in LDS behind the node window (stage_nodes): rotate the queried tree's to the
+  // front — where rays spend their time when a few instances sit under a real top-level tree (cornellbox) — and the
+  // instanced trees' behind them. Packet numbers are opaque to traversal (a leaf names its range), results unchanged.
+  {
+    const size_t n_top = scene.bvh.packets.size(), n_all = f.packets.size();
+    im.n_top_packets = uint32_t(n_top);
+    if (n_top && n_top < n_all) {
+      std::rotate(f.packets.begin(), f.packets.end() - n_top, f.packets.end());
+      for (Leaf &l : f.leaves)
+        if (l.pkt_count) l.pkt_first = l.pkt_first >= n_all - n_top ? uint32_t(l.pkt_first - (n_all - n_top)) : uint32_t(l.pkt_first + n_top);
+    }
+  }
   // kernels/traverse_pool.hip.h: the engine's LDS split. Deep stacks pay where rays spend their time inside
   // instances (thousands of placements); a handful of placements under a real top-level tree is still a flat scene.
   const bool many_instances = f.instances.size() >= 64;
@@ -463,6 +477,19 @@ int scene_image_check(const Scene &scene, uint64_t out[8]) {
     }
   for (size_t k = 0; k < f.leaves.size(); k++)
     if (leaf_refs[k] != 1) return fail("a leaf is not referenced exactly once", k, leaf_refs[k]);
+  for (const Leaf &lf : f.leaves)
+    if (lf.pkt_count && size_t(lf.pkt_first) + lf.pkt_count > f.packets.size()) return fail("a leaf's packet range", lf.pkt_first, lf.pkt_count);
+  if (im.me.root != CRT_INVALID_ID) {  // the queried tree's packets are the first ones of the array (the LDS packet window)
+    std::vector<uint32_t> q{im.me.root};
+    for (size_t h = 0; h < q.size(); h++)
+      for (int l = 0; l < 4; l++) {
+        const uint32_t lo = im.leaf_of_word[size_t(q[h]) * 4 + l];
+        const bool valid = (f.nodes[q[h]].flags >> l) & 1u, leaf = (f.nodes[q[h]].flags >> (4 + l)) & 1u;
+        if (valid && !leaf) q.push_back(f.nodes[q[h]].child[l]);
+        else if (valid && f.leaves[lo].pkt_count && f.leaves[lo].pkt_first + f.leaves[lo].pkt_count > im.n_top_packets)
+          return fail("a packet of the queried tree lies behind the instanced trees' packets", f.leaves[lo].pkt_first, im.n_top_packets);
+      }
+  }
   std::vector<uint8_t> is_root(f.nodes.size(), 0);
   if (im.me.root != CRT_INVALID_ID) { if (im.me.root != 0) return fail("the queried scene's root is not node 0", im.me.root, 0); is_root[0] = 1; }
   uint32_t staged = 0;

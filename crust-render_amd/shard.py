@@ -66,3 +66,31 @@ def gather_frame(film_local, width, height, rank, world, dist=None):
     """One-shot form of GatherPlan(...).gather(...): film_local [n_owned, 3] in shard_pixels order -> full frame on
     every rank. With world == 1 (or dist None) it is a local scatter."""
     return GatherPlan(width, height, world, film_local.device).gather(film_local, dist)
+
+
+def import_once(path, width=None, height=None, dist=None, src=0):
+    """The scene description of a multi-rank job, imported ONCE: rank `src` reads and composes the USD file
+    (usda.load: seconds for PointInstancedMedCity's crate, 14 s for the packed stress scene's 15.6 MB of text), every
+    other rank receives the result in one object broadcast instead of parsing the file again on its own cores.
+    The commit that follows (usda.build_world -> crt_commit) is deterministic (bvh.rs:22-24), so all ranks hold the same
+    tree. Without a process group (dist None or world 1) this is usda.load."""
+    from . import usda
+    if dist is None or dist.get_world_size() == 1:
+        return usda.load(path, width, height)
+    box = [usda.load(path, width, height) if dist.get_rank() == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+RAY_STATS_FIELDS = 8
+
+
+def reduce_ray_stats(stats, dist=None, device="cpu"):
+    """Sum of the ranks' RayStats (stats.rs:128-147: eight 64-bit counters, declaration order) — one all_reduce.
+    `stats`: a RayStats ctypes struct (or any object with its _fields_). Returns the eight totals as a list of int."""
+    import torch
+    vals = [int(getattr(stats, f)) for f, _t in stats._fields_][:RAY_STATS_FIELDS]
+    t = torch.tensor(vals, dtype=torch.int64, device=device)
+    if dist is not None and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [int(v) for v in t.cpu().tolist()]

@@ -92,3 +92,53 @@ def test_gather_to_rank0_reassembles_uneven_shards_gloo(tmp_path, world, w, h):
     i = np.arange(w * h)
     want = np.stack([i * 0.25, i + 0.5, i * -2.0], axis=1).astype(np.float32)
     assert np.array_equal(np.load(os.path.join(str(tmp_path), "frame_root.npy")), want)
+
+
+def _worker_import_once(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import pickle
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
+    crt = load_package()
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    if rank != 0:  # only rank 0 may touch the file
+        def refuse(*a, **k):
+            raise AssertionError("rank %d parsed the USD file itself" % rank)
+        crt.usda.load = refuse
+    desc = crt.shard.import_once(crt.scene_path("cornellbox_guided"), 96, 54, dist)
+    # the commit is each rank's own and deterministic: same tree everywhere (primitive counts and the image's statistics)
+    scene, mats, _protos = crt.usda.build_world(desc, crt, crt.default_material)
+    summary = dict(geoms=len(desc.geoms), lights=len(desc.lights), settings=desc.settings, mats=len(mats),
+                   prims=scene.primitive_count(), image=scene.image_check(),
+                   verts=[g["verts"].tobytes() for g in desc.geoms if g["kind"] == "mesh"])
+    with open(os.path.join(out_dir, "desc%d.pkl" % rank), "wb") as f:
+        pickle.dump(summary, f)
+    # the job's RayStats: eight 64-bit counters summed over the ranks in one all_reduce (stats.rs:128-147)
+    st = crt.CrtRayStats()
+    for k, (name, _t) in enumerate(st._fields_):
+        setattr(st, name, (rank + 1) * 10 ** k + (1 << 40) * (k == 1))
+    total = crt.shard.reduce_ray_stats(st, dist)
+    with open(os.path.join(out_dir, "stats%d.pkl" % rank), "wb") as f:
+        pickle.dump(total, f)
+    dist.destroy_process_group()
+
+
+def test_scene_is_imported_once_and_ray_stats_are_reduced_gloo(tmp_path):
+    """N > 1: rank 0 imports the USD file and broadcasts the description (the other rank's parser is disabled), both
+    ranks commit the same tree; the eight RayStats counters add up over the ranks (64-bit: closest_hit alone passes 2^32
+    within one bench step)."""
+    import pickle
+    import torch.multiprocessing as mp
+    port = 29700 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker_import_once, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    d = [pickle.load(open(os.path.join(str(tmp_path), "desc%d.pkl" % r), "rb")) for r in range(2)]
+    assert d[0] == d[1] and d[0]["geoms"] > 0 and d[0]["lights"] > 0
+    s = [pickle.load(open(os.path.join(str(tmp_path), "stats%d.pkl" % r), "rb")) for r in range(2)]
+    assert s[0] == s[1] == [3 * 10 ** k + (2 << 40) * (k == 1) for k in range(8)]
