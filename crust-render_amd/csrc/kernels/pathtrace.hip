@@ -83,6 +83,14 @@ __device__ __forceinline__ void st_nt(float *p, float v) {
   if (CRT_NT) __builtin_nontemporal_store(v, p);
   else *p = v;
 }
+// Hit records are the one stream written OUT OF ORDER (a ray's record goes out when its traversal ends): 16 + 4 bytes
+// into two planes, each a partial 32-byte sector. CRT_NT_HIT=0 writes them as plain stores, which L2 may merge with the
+// neighbouring slots' before they leave for HBM (A/B: profiles/README.md, round 3).
+#ifndef CRT_NT_HIT
+#define CRT_NT_HIT CRT_NT
+#endif
+__device__ __forceinline__ void st_hit(float4 *p, float4 v) { if (CRT_NT_HIT) st_nt(p, v); else *p = v; }
+__device__ __forceinline__ void st_hit(uint32_t *p, uint32_t v) { if (CRT_NT_HIT) st_nt(p, v); else *p = v; }
 __device__ __forceinline__ float4 ld_nt(const float4 *p) {
   if (CRT_NT) { const nt_f4 x = __builtin_nontemporal_load(reinterpret_cast<const nt_f4 *>(p)); return make_float4(x.x, x.y, x.z, x.w); }
   return *p;
@@ -183,6 +191,10 @@ struct Params {
   const uint8_t *mat_class;
   uint32_t partition;
   uint32_t class_stats;         // count Counters::cls_* in the vertex step (diagnostic, off by default)
+  // Per-stage pipeline, pinhole camera, no motion blur: a camera path is the 16 bytes (direction, sampler pattern) in
+  // plane `a` — its origin is the camera's, its throughput 1, its radiance 0, pixel / sample / depth follow from the slot
+  // number (generate_segment). Set per batch by Renderer::render.
+  uint32_t cam_compact;
 };
 
 __device__ __forceinline__ float light_weight(int s, float light_pdf, float bounce_pdf) {  // tracer.rs:85-92
@@ -326,49 +338,84 @@ inline uint8_t material_class(const CrtMaterial &m) {
   return 1;
 }
 
-// write_c: plane `c` of a camera path is a constant (throughput 1, radiance 0). The per-stage pipeline does not write
-// it here and does not read it in the first shade (17 GB less traffic per 531 M-path batch); the fused kernel keeps
-// the plain form — measured slower there with the special case (profiles/README.md, round 1).
+// One camera sample (tracer.rs:559-585): PathSampler::new(...).new_domain(tile), filter jitter, lens, primary ray, the
+// K_PATH domain's pattern. g = the sample's global number within the batch: active pixel g % n_act, sample g / n_act.
+struct CameraSample { V3 o, d; float time; uint32_t pattern, pix, sl; };
+__device__ __forceinline__ CameraSample camera_sample(const Params &P, size_t g, uint32_t sample_begin, const uint32_t *sobol_tab) {
+  CameraSample cs;
+  cs.pix = (uint32_t)(g % P.n_act); cs.sl = (uint32_t)(g / P.n_act);  // pix: active slot
+  const uint32_t lin = P.pixel_index[P.active ? P.active[cs.pix] : cs.pix];
+  const uint32_t px = lin % P.width, py = lin / P.width;
+  const int tile = (int)(px >> 8) + (int)(py >> 8) * 4096;  // tracer.rs:543
+  const Sampler root = new_domain(sampler_new((int)px, (int)py, P.frame, (int)(sample_begin + cs.sl)), tile);
+  float cam[4];
+  draw_sample4(new_domain(root, K_CAMERA), cam, sobol_tab);
+  const float fx = filter_offset(P.filter_kind, P.filter_radius, cam[0]);
+  const float fy = filter_offset(P.filter_kind, P.filter_radius, cam[1]);
+  const float u = ((float)px + fx) / (float)P.width;
+  const float v = ((float)py + fy) / (float)P.height;
+  cs.time = 0.0f;
+  if (P.has_motion) {  // tracer.rs:579-583
+    float t4[4];
+    draw_sample4(new_domain(root, K_TIME), t4, sobol_tab);
+    cs.time = t4[0];
+  }
+  camera_get_ray(P.camera, u, v, cam[2], cam[3], cs.o, cs.d);
+  cs.pattern = new_domain(root, K_PATH).pattern;  // tracer.rs:1101
+  return cs;
+}
+// Camera samples are dealt to the workgroup segments in round-robin chunks of one workgroup's width: slot k of
+// segment b holds global sample g = ((k / 256) * G + b) * 256 + k % 256. Every segment is then a uniform
+// sample of the frame (sky and geometry alike), so the per-segment work stays balanced at every bounce, while
+// a wave still holds 64 consecutive pixels of one 16x16 tile (coherent primary rays).
+__device__ __forceinline__ size_t camera_slot_sample(size_t k) {
+  return ((k / kBlock) * (size_t)gridDim.x + blockIdx.x) * kBlock + (k % kBlock);
+}
+
+// A compact camera path (Params::cam_compact) read back: direction and pattern from plane `a`, origin = the pinhole
+// camera's (camera_get_ray with no lens offset: origin + 0), pixel and sample from the slot's sample number (< 2^31:
+// ensure_buffers). D = plane d's words as generate would have written them.
+__device__ __forceinline__ void compact_camera_path(const Params &P, uint32_t k, float4 a, float4 &A, float4 &B, uint4 &D) {
+  const uint32_t g = (uint32_t)camera_slot_sample(k);
+  const V3 o = ld3(P.camera.origin) + splat(0.0f);
+  A = make_float4(o.x, o.y, o.z, a.x);
+  B = make_float4(a.y, a.z, 1.0f, 1.0f);
+  D = make_uint4(__float_as_uint(a.w), g % P.n_act, (P.max_depth & 0xffffu) << 16, g / P.n_act);
+}
+
+// Plane `c` of a camera path is a constant (throughput 1, radiance 0): the per-stage pipeline neither writes it here nor
+// reads it in its first shade (17 GB per 531 M-path batch, +1.3 %; the fused kernel keeps the plain form — measured
+// slower there with the special case). CRT_REGEN_FIRST=1 goes further — plane `d` (sampler pattern, pixel, depth, sample)
+// is not written either and the first shade reads NOTHING of the path state: it works the camera sample out again from
+// the slot number (Sobol tables in LDS). Measured on the bench (round 3, profiles/README.md): generate + resolve -1.2 ms
+// per step, shade +3 ms — the first shade is bound by its dependent round trips and barriers, not by the 68-116 bytes
+// per path this saves, and the ~350 more instructions per path are not free. Off.
+#ifndef CRT_REGEN_FIRST
+#define CRT_REGEN_FIRST 0
+#endif
+constexpr bool kRegenFirst = CRT_REGEN_FIRST != 0;
+static_assert(kBins == 1 || !CRT_REGEN_FIRST, "the first shade takes a camera path's sample number from its slot: one sub-segment per workgroup");
 __device__ __forceinline__ void generate_segment(const Params &P, const PathSoA &S, Counters *C, uint32_t sample_begin,
                                                  uint32_t n_samples, uint32_t *sobol_tab /* kSobolLdsWords */, bool write_c) {
   sobol_tables_init(sobol_tab);
-  // Camera samples are dealt to the workgroup segments in round-robin chunks of one workgroup's width: slot k of
-  // segment b holds global sample g = ((k / 256) * G + b) * 256 + k % 256. Every segment is then a uniform
-  // sample of the frame (sky and geometry alike), so the per-segment work stays balanced at every bounce, while
-  // a wave still holds 64 consecutive pixels of one 16x16 tile (coherent primary rays).
   const size_t total = (size_t)P.n_act * n_samples;
   const size_t seg0 = (size_t)blockIdx.x * kBins * P.seg_cap;  // camera rays are coherent as dealt: all in bin 0
-  const size_t G = gridDim.x;
   uint32_t seg_n = 0;
   for (size_t k = threadIdx.x; k < P.seg_cap; k += kBlock) {
-    const size_t g = ((k / kBlock) * G + blockIdx.x) * kBlock + (k % kBlock);
+    const size_t g = camera_slot_sample(k);
     if (g >= total) break;
     seg_n = (uint32_t)k + 1;
     const size_t i = seg0 + k;
-    const uint32_t pix = (uint32_t)(g % P.n_act), sl = (uint32_t)(g / P.n_act);  // pix: active slot
-    const uint32_t lin = P.pixel_index[P.active ? P.active[pix] : pix];
-    const uint32_t px = lin % P.width, py = lin / P.width;
-    const int tile = (int)(px >> 8) + (int)(py >> 8) * 4096;  // tracer.rs:543
-    const Sampler root = new_domain(sampler_new((int)px, (int)py, P.frame, (int)(sample_begin + sl)), tile);
-    float cam[4];
-    draw_sample4(new_domain(root, K_CAMERA), cam, sobol_tab);
-    const float fx = filter_offset(P.filter_kind, P.filter_radius, cam[0]);
-    const float fy = filter_offset(P.filter_kind, P.filter_radius, cam[1]);
-    const float u = ((float)px + fx) / (float)P.width;
-    const float v = ((float)py + fy) / (float)P.height;
-    float time = 0.0f;
-    if (P.has_motion) {  // tracer.rs:579-583
-      float t4[4];
-      draw_sample4(new_domain(root, K_TIME), t4, sobol_tab);
-      time = t4[0];
+    const CameraSample cs = camera_sample(P, g, sample_begin, sobol_tab);
+    if (!write_c && P.cam_compact) {  // 16 of the 48-64 bytes: the rest is constant or follows from the slot
+      st_nt(&S.a[i], make_float4(cs.d.x, cs.d.y, cs.d.z, __uint_as_float(cs.pattern)));
+      continue;
     }
-    V3 o, d;
-    camera_get_ray(P.camera, u, v, cam[2], cam[3], o, d);
-    st_nt(&S.a[i], make_float4(o.x, o.y, o.z, d.x));
-    st_nt(&S.b[i], make_float4(d.y, d.z, 1.0f, 1.0f));
+    st_nt(&S.a[i], make_float4(cs.o.x, cs.o.y, cs.o.z, cs.d.x));
+    st_nt(&S.b[i], make_float4(cs.d.y, cs.d.z, 1.0f, 1.0f));
     if (write_c) st_nt(&S.c[i], make_float4(1.0f, 0.0f, 0.0f, 0.0f));
-    st_nt(&S.d[i], make_uint4(new_domain(root, K_PATH).pattern /* tracer.rs:1101 */, pix, (P.max_depth & 0xffffu) << 16, sl));
-    if (P.has_motion) st_nt(&S.time[i], time);
+    if (write_c || !kRegenFirst) st_nt(&S.d[i], make_uint4(cs.pattern, cs.pix, (P.max_depth & 0xffffu) << 16, cs.sl));
+    if (P.has_motion) st_nt(&S.time[i], cs.time);
   }
   // live slots of this segment = 1 + the largest valid k over the workgroup (valid k form a prefix)
   __shared__ uint32_t seg_max;
@@ -409,19 +456,26 @@ __device__ __forceinline__ void extend_segment(const Params &P, const PathSoA &S
     uint32_t k;
     if (!lds_take(want, &next, n, k)) return false;
     const uint32_t i = bin_slot(k, pre, P.seg_cap);
-    const float4 A = ld_nt(&S.a[i]), B = ld_nt(&S.b[i]);
-    in.ox = A.x; in.oy = A.y; in.oz = A.z; in.dx = A.w; in.dy = B.x; in.dz = B.y;
-    in.time = P.has_motion ? S.time[i] : 0.0f;
+    if (first && P.cam_compact) {  // uniform: camera paths as 16-byte records (generate_segment)
+      const float4 A = ld_nt(&S.a[i]);
+      const V3 o = ld3(P.camera.origin) + splat(0.0f);
+      in.ox = o.x; in.oy = o.y; in.oz = o.z; in.dx = A.x; in.dy = A.y; in.dz = A.z;
+      in.time = 0.0f;
+    } else {
+      const float4 A = ld_nt(&S.a[i]), B = ld_nt(&S.b[i]);
+      in.ox = A.x; in.oy = A.y; in.oz = A.z; in.dx = A.w; in.dy = B.x; in.dz = B.y;
+      in.time = P.has_motion ? S.time[i] : 0.0f;
+    }
     in.mask = mask; in.t_min = 0.001f; in.t_max = CRT_INF; in.slot = i;
     return true;
   };
   auto emit = [&](uint32_t i, bool hit, const Hit &h, float dx, float dy, float dz) {
     if (hit) {
       const bool front = dot3(dx, dy, dz, h.nx, h.ny, h.nz) < 0.0f;  // scene.rs:356-359
-      st_nt(&H.h[i], make_float4(h.t, front ? h.nx : -h.nx, front ? h.ny : -h.ny, front ? h.nz : -h.nz));
-      st_nt(&H.geom[i], h.geom | (front ? 0x80000000u : 0u));
+      st_hit(&H.h[i], make_float4(h.t, front ? h.nx : -h.nx, front ? h.ny : -h.ny, front ? h.nz : -h.nz));
+      st_hit(&H.geom[i], h.geom | (front ? 0x80000000u : 0u));
     } else {
-      st_nt(&H.geom[i], kInvalid);
+      st_hit(&H.geom[i], kInvalid);
     }
     done++;
   };
@@ -521,14 +575,31 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
       uint32_t cls = 0;
       if (k_c < n) {
         const uint32_t i_c = bin_slot(k_c, pre, P.seg_cap);
-        const uint4 D = S.d[i_c];
         const uint32_t hg = H.geom[i_c];
         // the escaped arm's operands are requested together with the classification's (one memory round trip, not
         // two); for a path that hit something they are loaded again by the vertex step, from L2. (Requested for the
         // escaped lanes only — 48 B less per hit path — the per-stage shade is 1.5 % slower: profiles/README.md.)
-        float4 A = S.a[i_c], B = S.b[i_c], Cc = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
-        if (!first) Cc = S.c[i_c];
-        asm volatile("" : "+v"(A.x), "+v"(B.x), "+v"(Cc.x));
+        uint4 D;
+        float4 A, B, Cc = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+        if (first && P.cam_compact) {  // uniform
+          float4 a = S.a[i_c];
+          asm volatile("" : "+v"(a.x));
+          compact_camera_path(P, k_c, a, A, B, D);
+        } else if (!(kRegenFirst && first)) {
+          D = S.d[i_c]; A = S.a[i_c]; B = S.b[i_c];
+          if (!first) Cc = S.c[i_c];
+          asm volatile("" : "+v"(A.x), "+v"(B.x), "+v"(Cc.x));
+        } else {
+          // a camera path: only the direction (escaped rays) and the film slot are needed here, and both follow from the
+          // slot number; nothing of the path state is read (generate_segment)
+          D = make_uint4(0u, 0u, (P.max_depth & 0xffffu) << 16, 0u);
+          A = make_float4(0.0f, 0.0f, 0.0f, 0.0f); B = make_float4(0.0f, 0.0f, 1.0f, 1.0f);
+          if (hg == kInvalid && P.max_depth > 0) {
+            const CameraSample cs = camera_sample(P, camera_slot_sample(k_c), P.sample_begin, sobol_tab);
+            A.w = cs.d.x; B.x = cs.d.y; B.y = cs.d.z;
+            D.y = cs.pix; D.w = cs.sl;
+          }
+        }
         const int remaining = (int)(D.z >> 16);
         const bool carries_medium = MEDIA && (D.w >> kMediumShift) != 0;
         if (!INF && hg == kInvalid && remaining > 0 && !carries_medium) {
@@ -585,12 +656,22 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
     uint32_t meta = 0, aux = 0, pix = 0, pattern = 0, n_med = 0;
     bool n_delta = false, n_prev_valid = true;
     if (active) {
-      const float4 A = S.a[i], B = S.b[i];
-      float4 Cc = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
-      if (!first) Cc = S.c[i];
-      const uint4 D = S.d[i];
+      float4 A, B, Cc = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+      uint4 D;
+      if (first && P.cam_compact) {  // uniform
+        compact_camera_path(P, k_in, S.a[i], A, B, D);
+        time = 0.0f;
+      } else if (!(kRegenFirst && first)) {
+        A = S.a[i]; B = S.b[i]; D = S.d[i];
+        if (!first) Cc = S.c[i];
+        time = P.has_motion ? S.time[i] : 0.0f;
+      } else {  // a camera path: the sample is worked out again from the slot number (generate_segment)
+        const CameraSample cs = camera_sample(P, camera_slot_sample(k_in), P.sample_begin, sobol_tab);
+        A = make_float4(cs.o.x, cs.o.y, cs.o.z, cs.d.x); B = make_float4(cs.d.y, cs.d.z, 1.0f, 1.0f);
+        D = make_uint4(cs.pattern, cs.pix, (P.max_depth & 0xffffu) << 16, cs.sl);
+        time = cs.time;
+      }
       const V3 ro = v3(A.x, A.y, A.z), rd = v3(A.w, B.x, B.y);
-      time = P.has_motion ? S.time[i] : 0.0f;
       beta = v3(B.z, B.w, Cc.x);
       L = v3(Cc.y, Cc.z, Cc.w);
       pattern = D.x; pix = D.y; meta = D.z; aux = D.w;
@@ -1026,6 +1107,7 @@ struct Renderer {
   // `wide`), the batch whether the per-stage form pays: its 2-3 launches per bounce cost ~0.8 ms per batch, worth it from
   // `stage_min_paths` paths up. CRT_FUSED / CRT_WIDE / CRT_STAGE_MIN_PATHS override (A/B, per-stage timing, tests).
   bool wide = false;       // the scene's preference (wide_split)
+  bool cam_compact_ok = true;  // CRT_CAM_COMPACT
   int force_fused = -1;    // CRT_FUSED: -1 unset
   size_t stage_min_paths = (size_t)96 << 20;  // cornellbox 1080p, fused / per-stage Mray/s: 66 M paths 7507 / 7300, 133 M 7658 / 7900
   bool fused = true;       // what the LAST batch ran (crt_renderer_pipeline)
@@ -1143,6 +1225,8 @@ struct Renderer {
       if (rc != CRT_OK) return rc;
     }
     const bool wide = !fused && this->wide;  // per-stage launches take the scene's preferred traversal kernels
+    // camera paths as 16-byte records: per-stage launches, pinhole camera, static scene (CRT_CAM_COMPACT=0: A/B, tests)
+    p.cam_compact = (!fused && cam_compact_ok && !(P.camera.lens_radius > 0.0f) && !P.has_motion) ? 1u : 0u;
     // the film fold: plain sum, or with the luminance statistics and the stopping rule, then the new active list
     auto fold = [&]() -> int {
       if (!adaptive) {
@@ -1345,6 +1429,7 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
   // trip (profiles/README.md).
   r.wide = wide_split(P.scene);
   if (const char *e = getenv("CRT_WIDE")) r.wide = atoi(e) != 0;
+  if (const char *e = getenv("CRT_CAM_COMPACT")) r.cam_compact_ok = atoi(e) != 0;
   if (const char *e = getenv("CRT_FUSED")) r.force_fused = atoi(e) != 0 ? 1 : 0;
   if (const char *e = getenv("CRT_STAGE_MIN_PATHS")) r.stage_min_paths = (size_t)strtoull(e, nullptr, 10);
   // Workgroups per CU = queue segments per CU: Renderer::batch_grid.

@@ -236,8 +236,15 @@ __device__ __forceinline__ void instance_normal(const DevScene &S, uint32_t inst
 // primitive ids, masks) — on a small scene (veach_mis: 12 triangles) that is every node and every packet, so a ray
 // never leaves LDS until it reports its hit. Returns the nodes staged, n_pk the packets. Ends with a barrier.
 constexpr int kLdsPacketDwords = 48;
+#ifndef CRT_LDS_NODE_MAX
+#define CRT_LDS_NODE_MAX 1000000
+#endif
 __device__ __forceinline__ uint32_t stage_nodes(const DevScene &S, uint32_t *lds_nodes, int cap, uint32_t &n_pk) {
-  const uint32_t n = S.n_nodes < (uint32_t)cap ? S.n_nodes : (uint32_t)cap;
+  // CRT_LDS_NODE_MAX: at most this many nodes are staged, the rest of the window goes to the packets (which the upload
+  // orders hottest first, scene.cpp). Beyond the first two or three levels a node is visited by few rays, while the
+  // packets of a room's walls are tested by most of them.
+  uint32_t n = S.n_nodes < (uint32_t)cap ? S.n_nodes : (uint32_t)cap;
+  if (S.n_packets > 0 && n > (uint32_t)CRT_LDS_NODE_MAX) n = (uint32_t)CRT_LDS_NODE_MAX;
   const uint32_t room = ((uint32_t)cap - n) * (uint32_t)kLdsNodeStride / (uint32_t)kLdsPacketDwords;
   n_pk = S.n_packets < room ? S.n_packets : room;
   for (uint32_t w = threadIdx.x; w < n * 8u; w += blockDim.x) {  // 7 of the 8 x 16 bytes of a node

@@ -315,6 +315,32 @@ int flatten_image(const Scene &scene, FlatImage &im) {
       for (Leaf &l : f.leaves)
         if (l.pkt_count) l.pkt_first = l.pkt_first >= n_all - n_top ? uint32_t(l.pkt_first - (n_all - n_top)) : uint32_t(l.pkt_first + n_top);
     }
+    // ... and among the queried tree's packets, the leaves a ray is most likely to reach first: by the surface area of
+    // the leaf's box (the SAH's hit probability), largest first — the walls of a room before the detail inside it. Only
+    // the first packets fit the window; a leaf's packets stay consecutive. CRT_HOT_PACKETS=0: builder order (A/B).
+    static const bool hot_first = [] { const char *e = getenv("CRT_HOT_PACKETS"); return !e || atoi(e) != 0; }();
+    if (hot_first && n_top > 1) {
+      std::vector<std::pair<float, uint32_t>> order;  // (-area, leaf)
+      for (const WideNode &n : f.nodes)
+        for (int l = 0; l < 4; l++) {
+          if (!(n.flags & (1u << l)) || !(n.flags & (1u << (4 + l)))) continue;
+          const Leaf &lf = f.leaves[n.child[l]];
+          if (!lf.pkt_count || lf.pkt_first >= n_top) continue;
+          const float dx = n.bmax[0][l] - n.bmin[0][l], dy = n.bmax[1][l] - n.bmin[1][l], dz = n.bmax[2][l] - n.bmin[2][l];
+          order.emplace_back(-((dx * dy + dy * dz) + dz * dx), n.child[l]);
+        }
+      std::stable_sort(order.begin(), order.end());  // equal areas keep tree order
+      std::vector<Tri4> hot;
+      hot.reserve(n_top);
+      for (const auto &o : order) {
+        Leaf &lf = f.leaves[o.second];
+        const uint32_t at = uint32_t(hot.size());
+        hot.insert(hot.end(), f.packets.begin() + lf.pkt_first, f.packets.begin() + lf.pkt_first + lf.pkt_count);
+        lf.pkt_first = at;
+      }
+      if (hot.size() == n_top) std::copy(hot.begin(), hot.end(), f.packets.begin());
+      else return CRT_ERR_BAD_ARG;  // a packet of the queried tree that no leaf names: cannot happen with this builder
+    }
   }
   // kernels/traverse_pool.hip.h: the engine's LDS split. Deep stacks pay where rays spend their time inside
   // instances (thousands of placements); a handful of placements under a real top-level tree is still a flat scene.
