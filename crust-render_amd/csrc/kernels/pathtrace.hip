@@ -27,6 +27,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "shade.hip.h"
@@ -169,6 +171,11 @@ struct Params {
   uint32_t sample_begin;
   const CrtMaterial *materials;
   uint32_t n_materials;
+  // geom_id -> record of `materials` (and of `media`, `mat_class`), or nullptr: the table is indexed by geom_id itself.
+  // World::attach binds a material per geometry (rt_world.rs:111-122) and an instanced city binds the same few looks
+  // tens of thousands of times: PointInstancedMedCity has 40 008 geometry ids and 9.3 MB of records that are 133
+  // distinct ones or fewer — deduplicated (crt_renderer_new) the table stages in LDS like every other scene's.
+  const uint16_t *mat_index;
   const DevMedium *media;          // per geom_id: the material's interior medium (present == 0: none)
   const DevMedium *media_by_id;    // the present ones, by compact id - 1
   const CrtLight *lights;
@@ -617,7 +624,8 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
           pending = true;
           if (part && hg != kInvalid) {
             const uint32_t g = hg & 0x7fffffffu;
-            cls = cls_in_lds ? cls_lds[g] : P.mat_class[g];
+            const uint32_t mi_c = P.mat_index ? (uint32_t)P.mat_index[g] : g;
+            cls = cls_in_lds ? cls_lds[mi_c] : P.mat_class[mi_c];
           }
         }
       }
@@ -686,8 +694,10 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
       const uint32_t hg = H.geom[i];
       const bool has_hit = hg != kInvalid;
       const uint32_t geom = hg & 0x7fffffffu;
+      // the material record's index: the geometry id, or (deduplicated tables) one 2-byte load away
+      const uint32_t mat_i = (has_hit && P.mat_index) ? (uint32_t)P.mat_index[geom] : geom;
       if (P.class_stats) {  // uniform; diagnostic only
-        const uint32_t my = has_hit ? (uint32_t)P.mat_class[geom] : 0u;
+        const uint32_t my = has_hit ? (uint32_t)P.mat_class[P.mat_index ? (uint32_t)P.mat_index[geom] : geom] : 0u;
 #pragma unroll
         for (int c = 0; c < kClasses; c++) {
           const unsigned long long m = __ballot(my == (uint32_t)c);
@@ -728,7 +738,7 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
         if (prev_valid) {
           s_closest++;
           if (has_hit) {
-            const CrtMaterial &mat = mats[geom];
+            const CrtMaterial &mat = mats[mat_i];
             const float cos_o = fabs_(dot(normalize(rd), rec.normal));
             V3 emitted = mat_emitted_directional<SIMPLE>(mat, cos_o);
             if (len2(emitted) > 0.0f) {
@@ -780,7 +790,7 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
                                     : splat(0.0f) + sky_gradient(unit_direction);
           L = L + beta * background;
         } else {
-          const CrtMaterial &mat = mats[geom];
+          const CrtMaterial &mat = mats[mat_i];
           // tracer.rs:1352-1361: a scattering medium already paid e^{-sigma_bar t} through the free-flight
           // competition, only the chromatic correction remains; a clear one keeps pure Beer-Lambert.
           V3 atten = splat(1.0f);
@@ -847,7 +857,7 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
               alive = true;
               n_o = sample.origin; n_d = sample.dir; n_ppdf = sample.pdf; n_delta = sample.delta;
               // materials build the ray: it carries the interior only when it refracts into the front face
-              n_med = (MEDIA && sample.medium) ? P.media[geom].id : 0u;
+              n_med = (MEDIA && sample.medium) ? P.media[mat_i].id : 0u;
             }
           }
           s_vertices++;
@@ -1093,7 +1103,8 @@ struct Renderer {
   float4 *staging = nullptr;
   float4 *film = nullptr;
   CrtMaterial *d_materials = nullptr;
-  uint8_t *d_mat_class = nullptr;  // material_class() per geom_id
+  uint8_t *d_mat_class = nullptr;  // material_class() per record of d_materials
+  uint16_t *d_mat_index = nullptr; // geom_id -> record, when the table is deduplicated (Params::mat_index)
   DevMedium *d_media = nullptr;  // [n_materials] by geom_id, then [n_materials] by compact id
   bool has_media = false;
   int mats_kind = 1;  // 0 simple / 1 general / 2 general with interior media: which instance of the shading code runs
@@ -1129,6 +1140,7 @@ struct Renderer {
     if (film) (void)hipFree(film);
     if (d_materials) (void)hipFree(d_materials);
     if (d_mat_class) (void)hipFree(d_mat_class);
+    if (d_mat_index) (void)hipFree(d_mat_index);
     if (d_media) (void)hipFree(d_media);
     if (d_pstats) (void)hipFree(d_pstats);
     if (d_state) (void)hipFree(d_state);
@@ -1377,6 +1389,35 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
   ok = ok && CRT_HIP_OK(hipMalloc(&r.film, (size_t)P.n_pix * 16)) && CRT_HIP_OK(hipMemset(r.film, 0, (size_t)P.n_pix * 16));
   ok = ok && CRT_HIP_OK(hipMalloc(&r.d_pixels, (size_t)P.n_pix * 4)) &&
        CRT_HIP_OK(hipMemcpy(r.d_pixels, r.pixels.data(), (size_t)P.n_pix * 4, hipMemcpyHostToDevice));
+  // The material table: one record per geometry id, or — when that table would not fit shade's LDS arena and holds
+  // repeats — the distinct records and a 2-byte index per geometry id (Params::mat_index). Everything below that is
+  // "per material" (class byte, interior medium) is then per DISTINCT material. CRT_MAT_DEDUP=0: never (A/B, tests).
+  std::vector<CrtMaterial> unique_mats;
+  std::vector<uint16_t> mat_index;
+  {
+    bool dedup = n_materials > (size_t)mat_lds_max(kArenaDwords);
+    if (const char *e = getenv("CRT_MAT_DEDUP")) dedup = dedup && atoi(e) != 0;
+    if (dedup) {
+      auto bytes_of = [](const CrtMaterial &m) { return std::string(reinterpret_cast<const char *>(&m), sizeof(CrtMaterial)); };
+      std::unordered_map<std::string, uint32_t> seen;
+      mat_index.resize(n_materials);
+      for (size_t k = 0; k < n_materials && dedup; k++) {
+        auto it = seen.emplace(bytes_of(materials[k]), (uint32_t)unique_mats.size());
+        if (it.second) unique_mats.push_back(materials[k]);
+        if (unique_mats.size() > 0xffffu) dedup = false;  // a 2-byte index
+        mat_index[k] = (uint16_t)it.first->second;
+      }
+      if (!dedup || unique_mats.size() == n_materials) { unique_mats.clear(); mat_index.clear(); }
+    }
+  }
+  if (!unique_mats.empty()) {
+    ok = ok && CRT_HIP_OK(hipMalloc(&r.d_mat_index, n_materials * sizeof(uint16_t))) &&
+         CRT_HIP_OK(hipMemcpy(r.d_mat_index, mat_index.data(), n_materials * sizeof(uint16_t), hipMemcpyHostToDevice));
+    materials = unique_mats.data();
+    n_materials = unique_mats.size();
+    P.n_materials = (uint32_t)n_materials;
+  }
+  P.mat_index = r.d_mat_index;
   if (ok && n_materials) {
     ok = CRT_HIP_OK(hipMalloc(&r.d_materials, n_materials * sizeof(CrtMaterial))) &&
          CRT_HIP_OK(hipMemcpy(r.d_materials, materials, n_materials * sizeof(CrtMaterial), hipMemcpyHostToDevice));
