@@ -344,8 +344,13 @@ int flatten_image(const Scene &scene, FlatImage &im) {
   }
   // kernels/traverse_pool.hip.h: the engine's LDS split. Deep stacks pay where rays spend their time inside
   // instances (thousands of placements); a handful of placements under a real top-level tree is still a flat scene.
+  // ... and so do large trees: beyond a few thousand nodes a ray's stack regularly passes six entries, and every entry
+  // past the LDS part goes to private memory (round 3, Mray/s closest / any hit with 6 + 72 -> 10 + 16: 43 200 triangles
+  // in 3 600 nodes 3060 / 4618 -> 3286 / 4878, 7.08 M triangles 1789 / 2489 -> 2075 / 2982, the reference's stress scene
+  // through the integrator 2082 -> 2292; 1 728 spheres 4204 / 6618 -> 4200 / 6463: small trees keep the window).
   const bool many_instances = f.instances.size() >= 64;
-  uint32_t pool_stack = many_instances ? 10u : 6u;
+  const bool large_tree = f.nodes.size() > 2048;
+  uint32_t pool_stack = (many_instances || large_tree) ? 10u : 6u;
   if (const char *e = getenv("CRT_POOL_STACK_RT")) pool_stack = (uint32_t)atoi(e);  // A/B runs
   im.pool_stack = pool_stack;
   const bool deep = pool_stack >= 10u;  // run_traversal's rule for the window size
