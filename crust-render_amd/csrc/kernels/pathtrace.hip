@@ -330,7 +330,10 @@ constexpr int kClassLdsMax = 1024;                     // geom ids whose class b
 constexpr int mat_lds_max(int arena) { return (arena - kSobolLdsWords - kRingDwords - kClassLdsMax / 4) / (int)(sizeof(CrtMaterial) / 4); }
 // The per-stage shade kernel of simple-material scenes without lights at infinity also runs four workgroups per CU
 // (128 registers, a 40 KB arena: cornellbox +2 %); the other instances spill too much at 128 registers (sun_sky -16 %).
-constexpr int kArenaWide = 40 * 1024 / 4 - 256;
+#ifndef CRT_SHADE_WIDE_WAVES
+#define CRT_SHADE_WIDE_WAVES 4  // workgroups per CU of the WIDE shade kernel (5: 96 registers, a 31 KB arena — A/B, round 3)
+#endif
+constexpr int kArenaWide = (160 / CRT_SHADE_WIDE_WAVES) * 1024 / 4 - 256;
 static_assert(mat_lds_max(kArenaWide) >= 16 && mat_lds_max(kArenaDwords) >= 16, "the arena holds the Sobol tables, the rings and a material table");
 
 // Material class = which arms of the vertex code a hit on this material runs (openpbr.rs:1026-1136 dispatches one of
@@ -509,7 +512,8 @@ template <int MATS, bool INF, bool LIT, int ARENA>
 __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S, const PathSoA &N, const HitSoA &H,
                                               const ShadowSoA &Q, Counters *C, int cur, float4 *staging,
                                               uint32_t *sobol_tab /* ARENA dwords: Sobol tables, then the material table */,
-                                              bool first /* camera paths whose plane c was not written (generate_segment) */) {
+                                              bool first /* camera paths whose plane c was not written (generate_segment) */,
+                                              bool all_pending = false /* no CLASSIFY pass: every path takes the vertex step */) {
   constexpr bool MEDIA = MATS == 2, SIMPLE = MATS == 0;
   __shared__ uint32_t lds_ctr[10];  // [1] shadow requests, [2..8] statistics
   __shared__ uint32_t out_n[kBins];  // survivors per direction bin
@@ -580,7 +584,13 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
       next_in += kBlock;
       bool pending = false;
       uint32_t cls = 0;
-      if (k_c < n) {
+      // all_pending (per-stage pipeline, bounces after the first, one material class): CLASSIFY reads nothing and sends
+      // every path to the vertex step, whose own escaped arm adds the sky (same expression, same counters). The escaped
+      // lanes then idle through the vertex code of their wave — a quarter to a third of the lanes at bounces 1-3 of the
+      // bench — but the path state is read ONCE: CLASSIFY's 68 bytes per path were read a second time, from HBM, by the
+      // vertex step of every path that had hit something.
+      if (all_pending && !part) pending = k_c < n;
+      else if (k_c < n) {
         const uint32_t i_c = bin_slot(k_c, pre, P.seg_cap);
         const uint32_t hg = H.geom[i_c];
         // the escaped arm's operands are requested together with the classification's (one memory round trip, not
@@ -912,12 +922,12 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
     atomicAdd(&C->stats[threadIdx.x], (unsigned long long)lds_ctr[threadIdx.x + 1]);
 }
 template <int MATS, bool INF, bool WIDE, bool LIT>
-__global__ __launch_bounds__(kBlock, WIDE ? 4 : CRT_SHADE_WAVES) void k_shade(Params P, PathSoA S, PathSoA N, HitSoA H, ShadowSoA Q,
+__global__ __launch_bounds__(kBlock, WIDE ? CRT_SHADE_WIDE_WAVES : CRT_SHADE_WAVES) void k_shade(Params P, PathSoA S, PathSoA N, HitSoA H, ShadowSoA Q,
                                                                    Counters *C, int cur, float4 *staging, int first) {
   static_assert(LIT || !INF, "lights at infinity are lights");
   constexpr int ARENA = WIDE ? kArenaWide : kArenaDwords;
   __shared__ uint32_t sobol_tab[ARENA];
-  shade_segment<MATS, INF, LIT, ARENA>(P, S, N, H, Q, C, cur, staging, sobol_tab, first != 0);
+  shade_segment<MATS, INF, LIT, ARENA>(P, S, N, H, Q, C, cur, staging, sobol_tab, (first & 1) != 0, (first & 2) != 0);
 }
 
 // ---- shadow: World::occluded (rt_world.rs:235-237) for the queue; unoccluded requests pay out ----
@@ -978,13 +988,18 @@ __global__ __launch_bounds__(kBlock, WIDE ? 4 : CRT_SHADOW_WAVES) void k_shadow(
 // (profiles/README.md, "The round-2 nondeterminism"), so that kernel family is not built.
 template <int MATS, bool LIT>
 __global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_path(Params P, PathSoA S0, PathSoA S1, HitSoA H, ShadowSoA Q, Counters *C,
-                                                 float4 *staging, uint32_t sample_begin, uint32_t n_samples) {
+                                                 float4 *staging, uint32_t sample_begin, uint32_t n_samples,
+                                                 uint32_t start_it, int cur0) {
   __shared__ __attribute__((aligned(16))) uint32_t arena[kArenaDwords];
   __shared__ uint32_t live;
-  generate_segment(P, S0, C, sample_begin, n_samples, arena, true);
-  __syncthreads();
-  int cur = 0;
-  for (uint32_t it = 0; it <= P.max_depth; it++) {
+  // start_it > 0: the TAIL of a per-stage batch — the paths still alive after `start_it` bounces sit in buffer `cur0`
+  // of their segments (written by the last k_shade launch); this launch runs what is left of the path loop
+  if (start_it == 0) {
+    generate_segment(P, S0, C, sample_begin, n_samples, arena, true);
+    __syncthreads();
+  }
+  int cur = cur0;
+  for (uint32_t it = start_it; it <= P.max_depth; it++) {
     const PathSoA &S = cur ? S1 : S0;
     const PathSoA &N = cur ? S0 : S1;
     extend_segment<false, false>(P, S, H, C, cur, it == 0 ? 1 : 0, nullptr, arena);
@@ -1119,6 +1134,8 @@ struct Renderer {
   // `stage_min_paths` paths up. CRT_FUSED / CRT_WIDE / CRT_STAGE_MIN_PATHS override (A/B, per-stage timing, tests).
   bool wide = false;       // the scene's preference (wide_split)
   bool cam_compact_ok = true;  // CRT_CAM_COMPACT
+  int tail_from = 12;             // CRT_TAIL_FROM: the bounce from which a per-stage batch finishes in one fused launch
+  int noclassify_from = 1 << 30;  // CRT_NOCLASSIFY_FROM: per-stage shade without its CLASSIFY pass from this bounce on
   int force_fused = -1;    // CRT_FUSED: -1 unset
   size_t stage_min_paths = (size_t)96 << 20;  // cornellbox 1080p, fused / per-stage Mray/s: 66 M paths 7507 / 7300, 133 M 7658 / 7900
   bool fused = true;       // what the LAST batch ran (crt_renderer_pipeline)
@@ -1261,7 +1278,7 @@ struct Renderer {
     if (fused) {  // one launch for the whole path loop (class 0 of the profile), then the film fold
       timed(0, st, [&] {
 #define CRT_PATH(M, L) \
-  hipLaunchKernelGGL((k_path<M, L>), dim3(grid), dim3(kBlock), 0, st, p, S[0], S[1], H, Q, C, staging, sample_begin, n_samples)
+  hipLaunchKernelGGL((k_path<M, L>), dim3(grid), dim3(kBlock), 0, st, p, S[0], S[1], H, Q, C, staging, sample_begin, n_samples, 0u, 0)
         switch (mats_kind * 2 + (lit ? 1 : 0)) {
           case 0: CRT_PATH(0, false); break;
           case 1: CRT_PATH(0, true); break;
@@ -1276,14 +1293,36 @@ struct Renderer {
     }
     timed(3, st, [&] { hipLaunchKernelGGL(k_generate, dim3(grid), dim3(kBlock), 0, st, p, S[0], C, sample_begin, n_samples); });
     int cur = 0;
+    // The TAIL: from bounce `tail_from` on, what is left of the batch — roulette has ended all but a few paths per ten
+    // thousand by then (bench: 6.6 M of 531 M rays at bounce 4, 0.1 M at bounce 6) — runs as ONE launch of the fused
+    // path-loop kernel over the same segments instead of two or three launches per bounce up to the depth limit (bench,
+    // depth 32: 52 launches, ~2 ms of a 137 ms step). Not for the stats build (its kernels count) nor for lights at
+    // infinity (no fused instance). CRT_TAIL_FROM=n moves it (0: never).
+    const uint32_t tail_at = (tail_from > 0 && !d_tstats && !P.has_inf_lights) ? (uint32_t)tail_from : 0xffffffffu;
     for (uint32_t it = 0; it <= P.max_depth; it++) {
+      if (it >= tail_at) {
+        timed(3, st, [&] {
+#define CRT_TAIL(M, L) \
+  hipLaunchKernelGGL((k_path<M, L>), dim3(grid), dim3(kBlock), 0, st, p, S[0], S[1], H, Q, C, staging, sample_begin, n_samples, it, cur)
+          switch (mats_kind * 2 + (lit ? 1 : 0)) {
+            case 0: CRT_TAIL(0, false); break;
+            case 1: CRT_TAIL(0, true); break;
+            case 2: CRT_TAIL(1, false); break;
+            case 3: CRT_TAIL(1, true); break;
+            case 4: CRT_TAIL(2, false); break;
+            default: CRT_TAIL(2, true); break;
+          }
+#undef CRT_TAIL
+        });
+        break;
+      }
 #define CRT_EXTEND(ST, W) \
   timed(0, st, [&] { hipLaunchKernelGGL((k_extend<ST, W>), dim3(grid), dim3(kBlock), 0, st, p, S[cur], H, C, cur, it == 0 ? 1 : 0, d_tstats); })
       if (d_tstats) { if (wide) CRT_EXTEND(true, true); else CRT_EXTEND(true, false); }
       else { if (wide) CRT_EXTEND(false, true); else CRT_EXTEND(false, false); }
 #undef CRT_EXTEND
 #define CRT_SHADE(M, I, W, L) \
-  timed(1, st, [&] { hipLaunchKernelGGL((k_shade<M, I, W, L>), dim3(grid), dim3(kBlock), 0, st, p, S[cur], S[1 - cur], H, Q, C, cur, staging, it == 0 ? 1 : 0); })
+  timed(1, st, [&] { hipLaunchKernelGGL((k_shade<M, I, W, L>), dim3(grid), dim3(kBlock), 0, st, p, S[cur], S[1 - cur], H, Q, C, cur, staging, (it == 0 ? 1 : 0) | ((int)it >= noclassify_from ? 2 : 0)); })
       // the instance: material table (MATS), lights at infinity (INF), four waves (simple materials without lights at
       // infinity, when the scene runs the wide kernels), and — as for k_path — whether the light list is empty
       if (mats_kind == 2) { if (P.has_inf_lights) CRT_SHADE(2, true, false, true); else if (lit) CRT_SHADE(2, false, false, true); else CRT_SHADE(2, false, false, false); }
@@ -1471,6 +1510,8 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
   r.wide = wide_split(P.scene);
   if (const char *e = getenv("CRT_WIDE")) r.wide = atoi(e) != 0;
   if (const char *e = getenv("CRT_CAM_COMPACT")) r.cam_compact_ok = atoi(e) != 0;
+  if (const char *e = getenv("CRT_NOCLASSIFY_FROM")) r.noclassify_from = atoi(e);
+  if (const char *e = getenv("CRT_TAIL_FROM")) r.tail_from = atoi(e);
   if (const char *e = getenv("CRT_FUSED")) r.force_fused = atoi(e) != 0 ? 1 : 0;
   if (const char *e = getenv("CRT_STAGE_MIN_PATHS")) r.stage_min_paths = (size_t)strtoull(e, nullptr, 10);
   // Workgroups per CU = queue segments per CU: Renderer::batch_grid.

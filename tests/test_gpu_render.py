@@ -247,3 +247,36 @@ def test_shade_class_partition_keeps_waves_pure_and_bits_unchanged(crt):
     for k in seen:
         assert pure[k][1] > mixed[k][1], (k, pure[k], mixed[k])
     assert min(pure[k][1] for k in seen) > 0.5 and pure["base"][1] > 0.95
+
+
+@pytest.mark.parametrize("scene,res,base_env,knob", [
+    ("PointInstancedMedCity.usd", (96, 54, 6), {}, {"CRT_MAT_DEDUP": "0"}),                 # 40 008 records instead of the distinct ones
+    ("cornellbox.usda", (160, 90, 8), {"CRT_FUSED": "0"}, {"CRT_CAM_COMPACT": "0"}),       # camera paths as full records
+    ("cornellbox.usda", (160, 90, 8), {"CRT_FUSED": "0"}, {"CRT_NOCLASSIFY_FROM": "1"}),   # shade without its CLASSIFY pass
+    ("cornellbox.usda", (160, 90, 8), {"CRT_FUSED": "0"}, {"CRT_HOT_PACKETS": "0"}),       # packets in builder order
+    ("stress", (96, 54, 6), {}, {"CRT_POOL_STACK_RT": "6"}),                               # a large tree on the flat LDS split
+])
+def test_round3_knobs_change_no_bit(crt, scene, res, base_env, knob):
+    """Round 3's layout and scheduling choices — deduplicated material table, 16-byte camera paths, hot-first packet order,
+    the deep LDS split for large trees, shade's CLASSIFY pass — change WHEN and WHERE things are read, never a result: the
+    same render with the choice turned off gives the same image bits and the same eight counters."""
+    import subprocess
+    import sys
+    import json
+    w, h, depth = res
+    code = (
+        "import os, sys, json, numpy as np; sys.path.insert(0, %r); import torch\n"
+        "from __graft_entry__ import load_package; crt = load_package()\n"
+        "r, _ = crt.load_usda(crt.scene_path(%r) if not %r.endswith(('.usd', '.usda')) else os.path.join(%r, 'scenes', %r), %d, %d, %d)\n"
+        "r.render_samples(0, 8); torch.cuda.synchronize(); st = r.stats()\n"
+        "np.save(sys.argv[1], r.image())\n"
+        "print(json.dumps([getattr(st, f) for f, _t in st._fields_]))\n" % (ROOT, scene, scene, ROOT, scene, w, h, depth))
+    out = []
+    for k, extra in enumerate(({}, knob)):
+        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "crt_knob%d.npy" % k)
+        res_ = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **base_env, **extra), capture_output=True,
+                              text=True, timeout=300)
+        assert res_.returncode == 0, res_.stderr[-2000:]
+        out.append((np.load(path), json.loads(res_.stdout.strip().splitlines()[-1])))
+    assert out[0][1] == out[1][1], (knob, out[0][1], out[1][1])
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32)), knob

@@ -254,3 +254,28 @@ def test_single_ray_queries_from_concurrent_threads(crt):
     for t in threads:
         t.join()
     assert not errors, errors[:3]
+
+
+@pytest.mark.parametrize("n", [1, 63, 255, 256, 257, 1000, 70001])
+def test_ragged_batch_sizes_are_dealt_completely(crt, n):
+    """The batched queries deal their rays to the workgroups in round-robin 256-ray blocks (traverse.hip, dealt_ray):
+    every ray of a batch of any size — smaller than a block, a ragged last block, fewer blocks than workgroups — is
+    traced exactly once and lands in its own output slot."""
+    import torch
+    make, extent = scenes.ALL["mixed"]
+    o_scene, p_scene = make(ora), make(crt)
+    rays = fx.ray_batch(n, extent)
+    hf, ids, _front = o_scene.intersect_n(rays, 0.001, INF)
+    occ = o_scene.occluded_n(rays, 0.001, INF)
+    d_rays = crt.rays_to_device(rays)
+    d_hits = torch.full(((n + 3) * 40,), 0xAB, dtype=torch.uint8, device="cuda")  # guard records behind the batch
+    p_scene.intersect_n(d_rays, 0.001, INF, d_hits)
+    d_occ = torch.full((n + 3,), 7, dtype=torch.int32, device="cuda")
+    p_scene.occluded_n(d_rays, 0.001, INF, d_occ)
+    torch.cuda.synchronize()
+    hits = crt.hits_to_host(d_hits[: n * 40])
+    hit = ids[:, 0] != 0xFFFFFFFF
+    assert np.array_equal(hits["geom_id"], ids[:, 0]) and np.array_equal(hits["prim_id"], ids[:, 1])
+    assert np.array_equal(hits["t"][hit].view(np.uint32), hf[hit, 0].view(np.uint32))
+    assert np.array_equal(d_occ[:n].cpu().numpy().astype(np.uint8), occ)
+    assert bool((d_hits[n * 40:] == 0xAB).all()) and bool((d_occ[n:] == 7).all()), "a write behind the batch"
