@@ -23,6 +23,33 @@ def counts(a):
         prev = cur
         del r
 
+def work(a):
+    """Traversal work per ray at each bounce: the stats build's counters at depth k minus depth k-1."""
+    import torch
+    from __graft_entry__ import load_package
+    crt = load_package()
+    prev = None
+    for d in range(a.max + 1):
+        r, _ = crt.load_usda(crt.scene_path(a.scene), a.width, a.height, d)
+        ext, _sh = r.render_samples_stats(0, a.spp)
+        torch.cuda.synchronize()
+        cur = dict(rays=int(ext.rays), nodes=sum(ext.nodes), leaves=sum(ext.leaves), packets=sum(ext.packets), prims=sum(ext.prims),
+                   accepted=int(ext.accepted_hits), descents=int(ext.instance_descents),
+                   waves=[int(x) for x in ext.phase_waves], lanes=[int(x) for x in ext.phase_lanes], cyc=[int(x) for x in ext.phase_cycles])
+        if prev is None: dlt = cur
+        else: dlt = {k: (cur[k] - prev[k] if not isinstance(cur[k], list) else [x - y for x, y in zip(cur[k], prev[k])]) for k in cur}
+        n = max(dlt["rays"], 1)
+        util = ["%s %.2f" % (crt.CrtTravStats.PHASES[i][:6], dlt["lanes"][i] / (64.0 * dlt["waves"][i])) for i in range(7) if dlt["waves"][i]]
+        execs = ["%s %.2f" % (crt.CrtTravStats.PHASES[i][:6], dlt["waves"][i] * 64.0 / n) for i in range(7) if dlt["waves"][i]]
+        cyc = ["%s %.0f%%" % (crt.CrtTravStats.PHASES[i][:6], 100.0 * dlt["cyc"][i] / max(sum(dlt["cyc"]), 1)) for i in range(7) if dlt["waves"][i]]
+        print("bounce %d: rays %d | per ray: nodes %.2f leaves %.2f packets %.2f scalar %.2f accepted %.2f descents %.3f" % (
+            d, dlt["rays"], dlt["nodes"] / n, dlt["leaves"] / n, dlt["packets"] / n, dlt["prims"] / n, dlt["accepted"] / n, dlt["descents"] / n))
+        print("   lane utilisation: " + ", ".join(util))
+        print("   wave-executions x 64 per ray: " + ", ".join(execs))
+        print("   cycles: " + ", ".join(cyc))
+        prev = cur
+        del r
+
 def trace(a):
     rows = list(csv.DictReader(open(a.csv)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -42,6 +69,8 @@ ap = argparse.ArgumentParser()
 sub = ap.add_subparsers(dest="cmd")
 c = sub.add_parser("counts"); c.add_argument("--scene", default="cornellbox"); c.add_argument("--spp", type=int, default=256)
 c.add_argument("--width", type=int, default=1920); c.add_argument("--height", type=int, default=1080); c.add_argument("--max", type=int, default=8)
+wk = sub.add_parser("work"); wk.add_argument("--scene", default="cornellbox"); wk.add_argument("--spp", type=int, default=16)
+wk.add_argument("--width", type=int, default=1920); wk.add_argument("--height", type=int, default=1080); wk.add_argument("--max", type=int, default=4)
 t = sub.add_parser("trace"); t.add_argument("csv")
 a = ap.parse_args()
-counts(a) if a.cmd == "counts" else trace(a)
+{"counts": counts, "work": work, "trace": trace}[a.cmd](a)
