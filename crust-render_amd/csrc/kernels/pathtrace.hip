@@ -404,6 +404,12 @@ __device__ __forceinline__ void compact_camera_path(const Params &P, uint32_t k,
 #define CRT_REGEN_FIRST 0
 #endif
 constexpr bool kRegenFirst = CRT_REGEN_FIRST != 0;
+#ifndef CRT_CAM_COMPACT_BUILD
+#define CRT_CAM_COMPACT_BUILD 1  // 0: the 16-byte camera path form is compiled out of generate, extend and shade (A/B)
+#endif
+#ifndef CRT_MAT_INDEX_BUILD
+#define CRT_MAT_INDEX_BUILD 1    // 0: shade indexes the material table by geometry id only (A/B; the host then never deduplicates)
+#endif
 static_assert(kBins == 1 || !CRT_REGEN_FIRST, "the first shade takes a camera path's sample number from its slot: one sub-segment per workgroup");
 __device__ __forceinline__ void generate_segment(const Params &P, const PathSoA &S, Counters *C, uint32_t sample_begin,
                                                  uint32_t n_samples, uint32_t *sobol_tab /* kSobolLdsWords */, bool write_c) {
@@ -417,7 +423,7 @@ __device__ __forceinline__ void generate_segment(const Params &P, const PathSoA 
     seg_n = (uint32_t)k + 1;
     const size_t i = seg0 + k;
     const CameraSample cs = camera_sample(P, g, sample_begin, sobol_tab);
-    if (!write_c && P.cam_compact) {  // 16 of the 48-64 bytes: the rest is constant or follows from the slot
+    if (CRT_CAM_COMPACT_BUILD && !write_c && P.cam_compact) {  // 16 of the 48-64 bytes: the rest is constant or follows from the slot
       st_nt(&S.a[i], make_float4(cs.d.x, cs.d.y, cs.d.z, __uint_as_float(cs.pattern)));
       continue;
     }
@@ -466,7 +472,7 @@ __device__ __forceinline__ void extend_segment(const Params &P, const PathSoA &S
     uint32_t k;
     if (!lds_take(want, &next, n, k)) return false;
     const uint32_t i = bin_slot(k, pre, P.seg_cap);
-    if (first && P.cam_compact) {  // uniform: camera paths as 16-byte records (generate_segment)
+    if (CRT_CAM_COMPACT_BUILD && first && P.cam_compact) {  // uniform: camera paths as 16-byte records (generate_segment)
       const float4 A = ld_nt(&S.a[i]);
       const V3 o = ld3(P.camera.origin) + splat(0.0f);
       in.ox = o.x; in.oy = o.y; in.oz = o.z; in.dx = A.x; in.dy = A.y; in.dz = A.z;
@@ -515,6 +521,12 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
                                               bool first /* camera paths whose plane c was not written (generate_segment) */,
                                               bool all_pending = false /* no CLASSIFY pass: every path takes the vertex step */) {
   constexpr bool MEDIA = MATS == 2, SIMPLE = MATS == 0;
+  // Two of round 3's forms are compiled only into the instances that have registers to spare: the lit four-wave shade
+  // kernel sits at its 128-register limit with 17 spilled, and the few branches of either form cost it 3.6 % / 0.9 %
+  // (cornellbox_guided) where the unlit one gains 1 % (profiles/README.md). The host sets Params::cam_compact for
+  // unlit scenes only and runs a deduplicated table (Params::mat_index) through the three-wave shade kernel.
+  constexpr bool COMPACT = CRT_CAM_COMPACT_BUILD && !LIT;
+  constexpr bool MAT_INDEX = CRT_MAT_INDEX_BUILD && ARENA != kArenaWide;
   __shared__ uint32_t lds_ctr[10];  // [1] shadow requests, [2..8] statistics
   __shared__ uint32_t out_n[kBins];  // survivors per direction bin
   __shared__ uint32_t pre[kBins + 1];
@@ -598,7 +610,7 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
         // escaped lanes only — 48 B less per hit path — the per-stage shade is 1.5 % slower: profiles/README.md.)
         uint4 D;
         float4 A, B, Cc = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
-        if (first && P.cam_compact) {  // uniform
+        if (COMPACT && first && P.cam_compact) {  // uniform
           float4 a = S.a[i_c];
           asm volatile("" : "+v"(a.x));
           compact_camera_path(P, k_c, a, A, B, D);
@@ -634,7 +646,7 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
           pending = true;
           if (part && hg != kInvalid) {
             const uint32_t g = hg & 0x7fffffffu;
-            const uint32_t mi_c = P.mat_index ? (uint32_t)P.mat_index[g] : g;
+            const uint32_t mi_c = (MAT_INDEX && P.mat_index) ? (uint32_t)P.mat_index[g] : g;
             cls = cls_in_lds ? cls_lds[mi_c] : P.mat_class[mi_c];
           }
         }
@@ -676,7 +688,7 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
     if (active) {
       float4 A, B, Cc = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
       uint4 D;
-      if (first && P.cam_compact) {  // uniform
+      if (COMPACT && first && P.cam_compact) {  // uniform
         compact_camera_path(P, k_in, S.a[i], A, B, D);
         time = 0.0f;
       } else if (!(kRegenFirst && first)) {
@@ -705,9 +717,9 @@ __device__ __forceinline__ void shade_segment(const Params &P, const PathSoA &S,
       const bool has_hit = hg != kInvalid;
       const uint32_t geom = hg & 0x7fffffffu;
       // the material record's index: the geometry id, or (deduplicated tables) one 2-byte load away
-      const uint32_t mat_i = (has_hit && P.mat_index) ? (uint32_t)P.mat_index[geom] : geom;
+      const uint32_t mat_i = (MAT_INDEX && has_hit && P.mat_index) ? (uint32_t)P.mat_index[geom] : geom;
       if (P.class_stats) {  // uniform; diagnostic only
-        const uint32_t my = has_hit ? (uint32_t)P.mat_class[P.mat_index ? (uint32_t)P.mat_index[geom] : geom] : 0u;
+        const uint32_t my = has_hit ? (uint32_t)P.mat_class[(MAT_INDEX && P.mat_index) ? (uint32_t)P.mat_index[geom] : geom] : 0u;
 #pragma unroll
         for (int c = 0; c < kClasses; c++) {
           const unsigned long long m = __ballot(my == (uint32_t)c);
@@ -1254,8 +1266,9 @@ struct Renderer {
       if (rc != CRT_OK) return rc;
     }
     const bool wide = !fused && this->wide;  // per-stage launches take the scene's preferred traversal kernels
-    // camera paths as 16-byte records: per-stage launches, pinhole camera, static scene (CRT_CAM_COMPACT=0: A/B, tests)
-    p.cam_compact = (!fused && cam_compact_ok && !(P.camera.lens_radius > 0.0f) && !P.has_motion) ? 1u : 0u;
+    // camera paths as 16-byte records: per-stage launches of an UNLIT scene, pinhole camera, static scene
+    // (CRT_CAM_COMPACT=0: A/B, tests)
+    p.cam_compact = (CRT_CAM_COMPACT_BUILD && !fused && cam_compact_ok && P.n_lights == 0 && !(P.camera.lens_radius > 0.0f) && !P.has_motion) ? 1u : 0u;
     // the film fold: plain sum, or with the luminance statistics and the stopping rule, then the new active list
     auto fold = [&]() -> int {
       if (!adaptive) {
@@ -1328,7 +1341,7 @@ struct Renderer {
       if (mats_kind == 2) { if (P.has_inf_lights) CRT_SHADE(2, true, false, true); else if (lit) CRT_SHADE(2, false, false, true); else CRT_SHADE(2, false, false, false); }
       else if (mats_kind == 1) { if (P.has_inf_lights) CRT_SHADE(1, true, false, true); else if (lit) CRT_SHADE(1, false, false, true); else CRT_SHADE(1, false, false, false); }
       else if (P.has_inf_lights) CRT_SHADE(0, true, false, true);
-      else if (wide) { if (lit) CRT_SHADE(0, false, true, true); else CRT_SHADE(0, false, true, false); }
+      else if (wide && !P.mat_index) { if (lit) CRT_SHADE(0, false, true, true); else CRT_SHADE(0, false, true, false); }
       else { if (lit) CRT_SHADE(0, false, false, true); else CRT_SHADE(0, false, false, false); }
 #undef CRT_SHADE
       if (P.n_lights > 0 && P.strategy != CRT_STRATEGY_BSDF) {
@@ -1434,7 +1447,7 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
   std::vector<CrtMaterial> unique_mats;
   std::vector<uint16_t> mat_index;
   {
-    bool dedup = n_materials > (size_t)mat_lds_max(kArenaDwords);
+    bool dedup = CRT_MAT_INDEX_BUILD && n_materials > (size_t)mat_lds_max(kArenaDwords);
     if (const char *e = getenv("CRT_MAT_DEDUP")) dedup = dedup && atoi(e) != 0;
     if (dedup) {
       auto bytes_of = [](const CrtMaterial &m) { return std::string(reinterpret_cast<const char *>(&m), sizeof(CrtMaterial)); };
