@@ -156,7 +156,12 @@ struct DevScene {
   uint32_t pool_stack;   // LDS stack entries per ray the traversal engine uses for this scene (6 flat, 10 instanced)
   uint32_t n_packets;    // Tri4 packets, the queried tree's first (scene.cpp rotates them there; crt_scene_image_check): the first ones are staged in LDS behind the node window
   uint32_t direct_leaves;  // leaves without packets and with 1-3 scalar entries are encoded in the child word (below)
+  uint32_t cold;           // kCold* bits: the rarely used per-ray state a traversal of this scene can need (traverse_pool.hip.h)
 };
+// DevScene::cold. kColdUV: some triangle has shading normals (prim.rs:76-95 interpolates them with u, v). kColdNormal:
+// a sphere exists somewhere (its normal is computed at the hit and kept until emit), or instances nest deeper than one
+// level (a hit below the first level is taken to its parent's space at exit). kColdTime: a moving instance exists.
+enum : uint32_t { kColdUV = 1u, kColdNormal = 2u, kColdTime = 4u, kColdAll = 7u };
 // Device child words of a node: inner child = node index; leaf child = kLeafTag | leaf index; empty lane =
 // CRT_INVALID_ID. With DevScene::direct_leaves a leaf that holds no Tri4 packet and one to three scalar entries
 // (spheres, instances: every leaf of an instanced city's top-level tree) is written as

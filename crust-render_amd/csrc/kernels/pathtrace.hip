@@ -455,7 +455,9 @@ __global__ __launch_bounds__(kBlock) void k_generate(Params P, PathSoA S, Counte
 }
 
 // ---- extend: World::intersect (rt_world.rs:207-232) for every live path ----
-template <bool STATS, bool WIDE>
+// COMPACT: the 16-byte camera path form may occur (per-stage launches only: the fused kernel never sets it, and its
+// fetch has no registers for the branch — 13 -> 27, 33 -> 97, 52 -> 122 spilled registers in the lit k_path instances).
+template <bool STATS, bool WIDE, int COLD, bool COMPACT>
 __device__ __forceinline__ void extend_segment(const Params &P, const PathSoA &S, const HitSoA &H, Counters *C, int cur,
                                                int first, CrtTravStats *tstats, uint32_t *engine_lds) {
   __shared__ uint32_t pre[kBins + 1];
@@ -472,7 +474,7 @@ __device__ __forceinline__ void extend_segment(const Params &P, const PathSoA &S
     uint32_t k;
     if (!lds_take(want, &next, n, k)) return false;
     const uint32_t i = bin_slot(k, pre, P.seg_cap);
-    if (CRT_CAM_COMPACT_BUILD && first && P.cam_compact) {  // uniform: camera paths as 16-byte records (generate_segment)
+    if (CRT_CAM_COMPACT_BUILD && COMPACT && first && P.cam_compact) {  // uniform: camera paths as 16-byte records (generate_segment)
       const float4 A = ld_nt(&S.a[i]);
       const V3 o = ld3(P.camera.origin) + splat(0.0f);
       in.ox = o.x; in.oy = o.y; in.oz = o.z; in.dx = A.x; in.dy = A.y; in.dz = A.z;
@@ -495,16 +497,19 @@ __device__ __forceinline__ void extend_segment(const Params &P, const PathSoA &S
     }
     done++;
   };
-  run_traversal<false, STATS, WIDE>(P.scene, engine_lds, 0.001f, err, st, fetch, emit);
+  run_traversal<false, STATS, WIDE, COLD>(P.scene, engine_lds, 0.001f, err, st, fetch, emit);
   if (err) atomicOr(&C->err, err);
   if (STATS) flush_stats(st, tstats, done);
 }
 // WIDE: the four-workgroups-per-CU split of the engine (traverse_pool.hip.h), the per-stage pipeline of flat scenes.
-template <bool STATS, bool WIDE>
+// COLD: the cold per-ray state the scene can need (DevScene::cold; the hit record carries no u, v, so a scene needs
+// kColdUV only for shading normals): 0 for flat-shaded static triangle scenes, kColdNormal with spheres or nested
+// instances, kColdAll otherwise and for the stats build.
+template <bool STATS, bool WIDE, int COLD>
 __global__ __launch_bounds__(kBlock, WIDE ? 4 : CRT_EXTEND_WAVES) void k_extend(Params P, PathSoA S, HitSoA H, Counters *C, int cur,
                                                                      int first, CrtTravStats *tstats) {
   __shared__ __attribute__((aligned(16))) uint32_t engine_lds[WIDE ? kEngineLdsWide : kEngineLdsDwords];
-  extend_segment<STATS, WIDE>(P, S, H, C, cur, first, tstats, engine_lds);
+  extend_segment<STATS, WIDE, COLD, true>(P, S, H, C, cur, first, tstats, engine_lds);
 }
 
 // ---- shade: one iteration of trace_path's loop body for every live path (tracer.rs:1118-1530) ----
@@ -998,7 +1003,7 @@ __global__ __launch_bounds__(kBlock, WIDE ? 4 : CRT_SHADOW_WAVES) void k_shadow(
 // this code base ever showed — round 2, run-to-run differences of a few ulps — was confined to k_path<., LIT, INF> of
 // one build, whose per-stage launches of the same shade code were exact; its cause was never established
 // (profiles/README.md, "The round-2 nondeterminism"), so that kernel family is not built.
-template <int MATS, bool LIT>
+template <int MATS, bool LIT, int COLD>
 __global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_path(Params P, PathSoA S0, PathSoA S1, HitSoA H, ShadowSoA Q, Counters *C,
                                                  float4 *staging, uint32_t sample_begin, uint32_t n_samples,
                                                  uint32_t start_it, int cur0) {
@@ -1014,7 +1019,7 @@ __global__ __launch_bounds__(kBlock, CRT_EXTEND_WAVES) void k_path(Params P, Pat
   for (uint32_t it = start_it; it <= P.max_depth; it++) {
     const PathSoA &S = cur ? S1 : S0;
     const PathSoA &N = cur ? S0 : S1;
-    extend_segment<false, false>(P, S, H, C, cur, it == 0 ? 1 : 0, nullptr, arena);
+    extend_segment<false, false, COLD, false>(P, S, H, C, cur, it == 0 ? 1 : 0, nullptr, arena);
     __syncthreads();  // hit records of this segment are complete; the arena changes hands
     shade_segment<MATS, false, LIT, kArenaDwords>(P, S, N, H, Q, C, cur, staging, arena, false);
     __syncthreads();
@@ -1146,6 +1151,7 @@ struct Renderer {
   // `stage_min_paths` paths up. CRT_FUSED / CRT_WIDE / CRT_STAGE_MIN_PATHS override (A/B, per-stage timing, tests).
   bool wide = false;       // the scene's preference (wide_split)
   bool cam_compact_ok = true;  // CRT_CAM_COMPACT
+  int shade_wide = -1;            // CRT_SHADE_WIDE: 0 = the three-wave shade kernels even beside four-wave traversal kernels (A/B)
   int tail_from = 12;             // CRT_TAIL_FROM: the bounce from which a per-stage batch finishes in one fused launch
   int noclassify_from = 1 << 30;  // CRT_NOCLASSIFY_FROM: per-stage shade without its CLASSIFY pass from this bounce on
   int force_fused = -1;    // CRT_FUSED: -1 unset
@@ -1288,17 +1294,22 @@ struct Renderer {
       return CRT_OK;
     };
     const bool lit = P.n_lights > 0;  // the kernel instance; whether the strategy samples the lights is checked in shade
+    // the cold per-ray state the scene can need (DevScene::cold) picks the closest-hit kernels' instance: none / the
+    // pending normal only / everything for the per-stage k_extend, none / everything for the fused kernel of simple scenes
+    const int scene_cold = (int)P.scene.cold;
+    const int ext_cold = scene_cold == 0 ? 0 : (scene_cold == (int)kColdNormal ? (int)kColdNormal : (int)kColdAll);
+    const int path_cold = scene_cold == 0 ? 0 : (int)kColdAll;
     if (fused) {  // one launch for the whole path loop (class 0 of the profile), then the film fold
       timed(0, st, [&] {
-#define CRT_PATH(M, L) \
-  hipLaunchKernelGGL((k_path<M, L>), dim3(grid), dim3(kBlock), 0, st, p, S[0], S[1], H, Q, C, staging, sample_begin, n_samples, 0u, 0)
+#define CRT_PATH(M, L, CO) \
+  hipLaunchKernelGGL((k_path<M, L, CO>), dim3(grid), dim3(kBlock), 0, st, p, S[0], S[1], H, Q, C, staging, sample_begin, n_samples, 0u, 0)
         switch (mats_kind * 2 + (lit ? 1 : 0)) {
-          case 0: CRT_PATH(0, false); break;
-          case 1: CRT_PATH(0, true); break;
-          case 2: CRT_PATH(1, false); break;
-          case 3: CRT_PATH(1, true); break;
-          case 4: CRT_PATH(2, false); break;
-          default: CRT_PATH(2, true); break;
+          case 0: if (path_cold == 0) CRT_PATH(0, false, 0); else CRT_PATH(0, false, kColdAll); break;
+          case 1: if (path_cold == 0) CRT_PATH(0, true, 0); else CRT_PATH(0, true, kColdAll); break;
+          case 2: CRT_PATH(1, false, kColdAll); break;
+          case 3: CRT_PATH(1, true, kColdAll); break;
+          case 4: CRT_PATH(2, false, kColdAll); break;
+          default: CRT_PATH(2, true, kColdAll); break;
         }
 #undef CRT_PATH
       });
@@ -1315,24 +1326,25 @@ struct Renderer {
     for (uint32_t it = 0; it <= P.max_depth; it++) {
       if (it >= tail_at) {
         timed(3, st, [&] {
-#define CRT_TAIL(M, L) \
-  hipLaunchKernelGGL((k_path<M, L>), dim3(grid), dim3(kBlock), 0, st, p, S[0], S[1], H, Q, C, staging, sample_begin, n_samples, it, cur)
+#define CRT_TAIL(M, L, CO) \
+  hipLaunchKernelGGL((k_path<M, L, CO>), dim3(grid), dim3(kBlock), 0, st, p, S[0], S[1], H, Q, C, staging, sample_begin, n_samples, it, cur)
           switch (mats_kind * 2 + (lit ? 1 : 0)) {
-            case 0: CRT_TAIL(0, false); break;
-            case 1: CRT_TAIL(0, true); break;
-            case 2: CRT_TAIL(1, false); break;
-            case 3: CRT_TAIL(1, true); break;
-            case 4: CRT_TAIL(2, false); break;
-            default: CRT_TAIL(2, true); break;
+            case 0: if (path_cold == 0) CRT_TAIL(0, false, 0); else CRT_TAIL(0, false, kColdAll); break;
+            case 1: if (path_cold == 0) CRT_TAIL(0, true, 0); else CRT_TAIL(0, true, kColdAll); break;
+            case 2: CRT_TAIL(1, false, kColdAll); break;
+            case 3: CRT_TAIL(1, true, kColdAll); break;
+            case 4: CRT_TAIL(2, false, kColdAll); break;
+            default: CRT_TAIL(2, true, kColdAll); break;
           }
 #undef CRT_TAIL
         });
         break;
       }
-#define CRT_EXTEND(ST, W) \
-  timed(0, st, [&] { hipLaunchKernelGGL((k_extend<ST, W>), dim3(grid), dim3(kBlock), 0, st, p, S[cur], H, C, cur, it == 0 ? 1 : 0, d_tstats); })
-      if (d_tstats) { if (wide) CRT_EXTEND(true, true); else CRT_EXTEND(true, false); }
-      else { if (wide) CRT_EXTEND(false, true); else CRT_EXTEND(false, false); }
+#define CRT_EXTEND(ST, W, CO) \
+  timed(0, st, [&] { hipLaunchKernelGGL((k_extend<ST, W, CO>), dim3(grid), dim3(kBlock), 0, st, p, S[cur], H, C, cur, it == 0 ? 1 : 0, d_tstats); })
+      if (d_tstats) { if (wide) CRT_EXTEND(true, true, kColdAll); else CRT_EXTEND(true, false, kColdAll); }
+      else if (wide) { if (ext_cold == 0) CRT_EXTEND(false, true, 0); else if (ext_cold == (int)kColdNormal) CRT_EXTEND(false, true, kColdNormal); else CRT_EXTEND(false, true, kColdAll); }
+      else { if (ext_cold == 0) CRT_EXTEND(false, false, 0); else if (ext_cold == (int)kColdNormal) CRT_EXTEND(false, false, kColdNormal); else CRT_EXTEND(false, false, kColdAll); }
 #undef CRT_EXTEND
 #define CRT_SHADE(M, I, W, L) \
   timed(1, st, [&] { hipLaunchKernelGGL((k_shade<M, I, W, L>), dim3(grid), dim3(kBlock), 0, st, p, S[cur], S[1 - cur], H, Q, C, cur, staging, (it == 0 ? 1 : 0) | ((int)it >= noclassify_from ? 2 : 0)); })
@@ -1341,7 +1353,7 @@ struct Renderer {
       if (mats_kind == 2) { if (P.has_inf_lights) CRT_SHADE(2, true, false, true); else if (lit) CRT_SHADE(2, false, false, true); else CRT_SHADE(2, false, false, false); }
       else if (mats_kind == 1) { if (P.has_inf_lights) CRT_SHADE(1, true, false, true); else if (lit) CRT_SHADE(1, false, false, true); else CRT_SHADE(1, false, false, false); }
       else if (P.has_inf_lights) CRT_SHADE(0, true, false, true);
-      else if (wide && !P.mat_index) { if (lit) CRT_SHADE(0, false, true, true); else CRT_SHADE(0, false, true, false); }
+      else if (wide && !P.mat_index && shade_wide != 0) { if (lit) CRT_SHADE(0, false, true, true); else CRT_SHADE(0, false, true, false); }
       else { if (lit) CRT_SHADE(0, false, false, true); else CRT_SHADE(0, false, false, false); }
 #undef CRT_SHADE
       if (P.n_lights > 0 && P.strategy != CRT_STRATEGY_BSDF) {
@@ -1521,10 +1533,13 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
   // scene of analytic spheres only (openpbr_showcase: next to no traversal, all shading) 1 % to the hit records' round
   // trip (profiles/README.md).
   r.wide = wide_split(P.scene);
-  if (const char *e = getenv("CRT_WIDE")) r.wide = atoi(e) != 0;
+  // CRT_WIDE=1 forces the four-wave kernels (A/B, tests) — except on a direct-leaf scene: those kernels are built
+  // without the direct form (run_traversal) and must never meet a direct child word
+  if (const char *e = getenv("CRT_WIDE")) r.wide = atoi(e) != 0 && P.scene.direct_leaves == 0;
   if (const char *e = getenv("CRT_CAM_COMPACT")) r.cam_compact_ok = atoi(e) != 0;
   if (const char *e = getenv("CRT_NOCLASSIFY_FROM")) r.noclassify_from = atoi(e);
   if (const char *e = getenv("CRT_TAIL_FROM")) r.tail_from = atoi(e);
+  if (const char *e = getenv("CRT_SHADE_WIDE")) r.shade_wide = atoi(e) != 0 ? 1 : 0;
   if (const char *e = getenv("CRT_FUSED")) r.force_fused = atoi(e) != 0 ? 1 : 0;
   if (const char *e = getenv("CRT_STAGE_MIN_PATHS")) r.stage_min_paths = (size_t)strtoull(e, nullptr, 10);
   // Workgroups per CU = queue segments per CU: Renderer::batch_grid.

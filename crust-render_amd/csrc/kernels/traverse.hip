@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kBlock, WIDE ? 4 : 3) void occluded_n_kernel(DevSce
 // Small flat triangle scenes run the WIDE kernels (four workgroups resident per CU), the others the scene's own split
 // on three (crt_internal.h, wide_split).
 bool wide_scene(const DevScene &s) {
-  if (const char *e = getenv("CRT_WIDE")) return atoi(e) != 0;  // A/B runs, tests
+  if (const char *e = getenv("CRT_WIDE")) return atoi(e) != 0 && s.direct_leaves == 0;  // A/B runs, tests; never a direct-leaf scene (run_traversal)
   return wide_split(s);
 }
 int grid_for(size_t n, bool wide) {

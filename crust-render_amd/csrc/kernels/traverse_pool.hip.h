@@ -109,7 +109,13 @@ __device__ __forceinline__ int wave_count(bool p) {
   return n;
 }
 
-template <bool ANY, bool STATS, int ROWS, bool DIRECT, bool LEAN, class Fetch, class Emit>
+// COLD: which of the rarely used per-ray fields this instantiation keeps at all (DevScene::cold, crt_internal.h) —
+// kColdUV the hit's barycentrics (read only by smooth shading normals and by the batched query's output), kColdNormal
+// the pending normal of a sphere or of a hit below the first instance level, kColdTime the shutter time. They are 4 + 8
+// + 2 of the 28 registers of per-ray cold state a lane carries through every phase; a flat-shaded triangle scene with
+// one level of instances (cornellbox, the stress scene, PointInstancedMedCity) needs none of them, and without them the
+// four-wave kernel's 32 spilled registers are 0 (round 3: bench extend 87.8 -> 79.6 ms per step, MedCity +3.9 %).
+template <bool ANY, bool STATS, int ROWS, bool DIRECT, bool LEAN, int COLD, class Fetch, class Emit>
 __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's pool_lds_dwords<ROWS>() */, float t_min,
                               const uint32_t *lds_nodes /* staged top of the tree */, uint32_t n_lds,
                               uint32_t n_lds_pk /* packets staged behind the n_lds nodes */, uint32_t pstack,
@@ -140,13 +146,23 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
   // side_d / side_n / best live in registers. Indexed by a run-time row they would be read and written through
   // compare-and-select chains over ALL their elements (what the compiler makes of a dynamic index into a promoted
   // array: 30 instructions per store); with the row loop unrolled each access is one select per row.
+  // Fields this instantiation does not keep read as zero and are never written (COLD): the scene cannot reach the
+  // code that would use them (no sphere, no smooth normal, no moving instance, no second instance level).
+  auto cold_dead = [&](auto &arr, int f) {
+    if ((void *)&arr == (void *)&side_n) return !(COLD & kColdNormal);
+    if ((void *)&arr == (void *)&side_d) return f == 3 && !(COLD & kColdTime);
+    if ((void *)&arr == (void *)&best) return (f == B_BU || f == B_BV) && !(COLD & kColdUV);
+    return false;
+  };
   auto rd = [&](auto &arr, int row, int f) {
     auto r = arr[0][f];
+    if (cold_dead(arr, f)) return (decltype(r))0;
 #pragma unroll
     for (int k = 1; k < ROWS; k++) r = row == k ? arr[k][f] : r;
     return r;
   };
   auto wr = [&](auto &arr, int row, int f, auto val) {
+    if (cold_dead(arr, f)) return;
 #pragma unroll
     for (int k = 0; k < ROWS; k++) arr[k][f] = row == k ? (decltype(arr[k][f] + 0))val : arr[k][f];
   };
@@ -931,7 +947,7 @@ static_assert(kEngineLdsWide * 4 + 512 <= 40 * 1024, "four workgroups of the wid
 // Runs the traversal for one workgroup. `lds` = kEngineLdsDwords dwords (WIDE: kEngineLdsWide), 16-byte aligned.
 // Contains a workgroup barrier: call from uniform control flow, after the shared variables the callbacks use are
 // initialised.
-template <bool ANY, bool STATS, bool WIDE, class Fetch, class Emit>
+template <bool ANY, bool STATS, bool WIDE, int COLD = (int)kColdAll, class Fetch, class Emit>
 __device__ __forceinline__ void run_traversal(const DevScene &S, uint32_t *lds, float t_min, uint32_t &err, LaneStats &st,
                                               Fetch fetch, Emit emit) {
   // the split of the arena is the scene's (uniform): clamp to what the arena was sized for
@@ -947,10 +963,15 @@ __device__ __forceinline__ void run_traversal(const DevScene &S, uint32_t *lds, 
   // that knows nothing of either — carrying the direct form's state through the node loop costs the bench scene 2 %,
   // the root test 1.5 % (profiles/README.md).
   uint32_t *wave_lds = lds + (threadIdx.x >> 6) * wave_dwords;
-  if (CRT_DIRECT_LEAVES != 0 && S.direct_leaves != 0)
-    traverse_pool<ANY, STATS, CRT_POOL_ROWS, true, WIDE>(S, wave_lds, t_min, lds_nodes, n_lds, n_lds_pk, pstack, err, st, fetch, emit);
-  else
-    traverse_pool<ANY, STATS, CRT_POOL_ROWS, false, WIDE>(S, wave_lds, t_min, lds_nodes, n_lds, n_lds_pk, pstack, err, st, fetch, emit);
+  // COLD (what cold per-ray state the engine keeps, see traverse_pool) is the KERNEL's: the renderer's closest-hit
+  // kernels are instantiated per DevScene::cold and chosen on the host — several engine copies inside one kernel cost
+  // the register allocator more than the leaner copy saves (the fused kernel went from 11 to 89 spilled registers).
+  // Any-hit traversal keeps none of that state by construction; the batched queries report u and v and take kColdAll.
+  // The four-wave kernels never meet a direct-leaf scene (wide_split, crt_internal.h).
+#define CRT_ENGINE(D) traverse_pool<ANY, STATS, CRT_POOL_ROWS, D, WIDE, COLD>(S, wave_lds, t_min, lds_nodes, n_lds, n_lds_pk, pstack, err, st, fetch, emit)
+  if (CRT_DIRECT_LEAVES != 0 && !WIDE && S.direct_leaves != 0) CRT_ENGINE(true);
+  else CRT_ENGINE(false);
+#undef CRT_ENGINE
 }
 
 }  // namespace dev

@@ -297,7 +297,16 @@ struct FlatImage {
   std::vector<uint32_t> leaf_of_word;  // per node lane (4 per node): the Leaf a leaf child word stands for, else ~0
   uint32_t n_staged_roots = 0;
   uint32_t n_top_packets = 0;  // the queried scene's own Tri4 packets: the first ones of the array
+  uint32_t cold = kColdAll;    // DevScene::cold
 };
+
+// Levels of instancing below `s` (0: no instance anywhere in it).
+uint32_t instance_levels(const Scene &s) {
+  uint32_t d = 0;
+  for (const Prim &p : s.bvh.prims)
+    if (p.kind == PRIM_INSTANCE && p.scene) d = std::max(d, 1u + instance_levels(*p.scene));
+  return d;
+}
 
 int flatten_image(const Scene &scene, FlatImage &im) {
   Flat &f = im.f;
@@ -446,6 +455,19 @@ int flatten_image(const Scene &scene, FlatImage &im) {
         n.child[l] |= 0x80000000u;
       }
     }
+  }
+  // What cold per-ray state a traversal of this image can need (crt_internal.h, kCold*): decided here, where every
+  // primitive of every nested scene is in one array. CRT_COLD=7 keeps everything (A/B, tests).
+  {
+    uint32_t cold = 0;
+    for (const DevPrim &d : f.prims) {
+      if (d.kind == PRIM_SPHERE) cold |= kColdNormal;
+      if (d.kind == PRIM_TRI && f2u(d.d[9]) != 0xFFFFFFFFu) cold |= kColdUV;
+    }
+    if (instance_levels(scene) > 1) cold |= kColdNormal;
+    if (!f.moving.empty()) cold |= kColdTime;
+    if (const char *e = getenv("CRT_COLD")) cold |= (uint32_t)atoi(e) & kColdAll;
+    im.cold = cold;
   }
   // placements of the moving instances: behind the shading normals, addressed through the instance's flags word
   for (const auto &mv : f.moving) {
@@ -599,6 +621,7 @@ int Scene::ensure_device() {
   img->view.n_packets = uint32_t(f.packets.size());
   img->view.direct_leaves = im.direct ? 1u : 0u;
   img->view.pool_stack = im.pool_stack;
+  img->view.cold = im.cold;
   dev = std::move(img);
   return CRT_OK;
 }
