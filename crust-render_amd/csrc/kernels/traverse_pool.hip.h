@@ -968,7 +968,10 @@ __device__ __forceinline__ void run_traversal(const DevScene &S, uint32_t *lds, 
   // the register allocator more than the leaner copy saves (the fused kernel went from 11 to 89 spilled registers).
   // Any-hit traversal keeps none of that state by construction; the batched queries report u and v and take kColdAll.
   // The four-wave kernels never meet a direct-leaf scene (wide_split, crt_internal.h).
-#define CRT_ENGINE(D) traverse_pool<ANY, STATS, CRT_POOL_ROWS, D, WIDE, COLD>(S, wave_lds, t_min, lds_nodes, n_lds, n_lds_pk, pstack, err, st, fetch, emit)
+#ifndef CRT_WIDE_LEAN
+#define CRT_WIDE_LEAN 1  // the four-wave kernels fetch a packet in stages (LEAN); 0: whole, as the three-wave ones (A/B)
+#endif
+#define CRT_ENGINE(D) traverse_pool<ANY, STATS, CRT_POOL_ROWS, D, (WIDE && CRT_WIDE_LEAN != 0), COLD>(S, wave_lds, t_min, lds_nodes, n_lds, n_lds_pk, pstack, err, st, fetch, emit)
   if (CRT_DIRECT_LEAVES != 0 && !WIDE && S.direct_leaves != 0) CRT_ENGINE(true);
   else CRT_ENGINE(false);
 #undef CRT_ENGINE
