@@ -5,10 +5,11 @@
 
 Workload (config.workload): samples/cornellbox.usda at 1920x1080, scene-default depth 32, triangle filter r=1,
 adaptive stopping off (variance 0), frame 0. A "step" is ONE wavefront batch: `--spp-per-step` samples (default
-256) of every pixel a rank owns — generate, then up to depth+1 rounds of extend / shade / shadow, then the film
-fold — with the scene, the path-state planes (87 GB at this size: batches are sized for 288 GB of HBM — longer queue
-segments drain the traversal's ray pools less often: 128 / 192 / 256 spp per batch measure 8179 / 8258 / 8430 Mray/s,
-profiles/README.md) and the film resident in HBM before the timed region starts. 1024 spp is 4 such steps, the default K.
+512) of every pixel a rank owns — generate, then up to depth+1 rounds of extend / shade / shadow, then the film
+fold — with the scene, the path-state planes (174 GB at this size: batches are sized for 288 GB of HBM — a launch's
+ramp-up and drain are paid once per batch and bounce: 256 / 384 / 512 / 640 / 768 spp per batch measure 9307 / 9529 /
+9832 / 9919 / 9970 Mray/s, profiles/README.md; a part with less free HBM halves the batch until it fits) and the film
+resident in HBM before the timed region starts. 1024 spp is 2 such steps; the default K of 4 is 2048 spp.
 
 Metric (stats.rs:150-152): Mray/s = (closest_hit + shadow_rays) / render seconds / 1e6, summed
 over all ranks; the timed region is K steps bracketed by barrier + synchronize, MAX over ranks.
@@ -46,7 +47,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp-per-step", type=int, default=256)
+    ap.add_argument("--spp-per-step", type=int, default=512)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default="cornellbox")
@@ -106,7 +107,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # A part with less free HBM than the batch needs (the default shape holds 87 GB of path state) halves the batch until
+    # A part with less free HBM than the batch needs (the default shape holds 174 GB of path state) halves the batch until
     # it fits; the shape actually run is what the line reports (config.spp_per_step).
     requested = args.spp_per_step
     while True:

@@ -19,7 +19,7 @@ case $PART in
   rm -f profiles/r03_pmc_bench.json
   bash profiles/pmc_r03.sh $T cb stress
   python bench.py > gpurun_out/${T}_bench_default.json 2> gpurun_out/${T}_bench.err
-  python bench.py --scene stress --spp-per-step 64 > gpurun_out/${T}_bench_stress.json 2>> gpurun_out/${T}_bench.err
+  python bench.py --scene stress --spp-per-step 256 > gpurun_out/${T}_bench_stress.json 2>> gpurun_out/${T}_bench.err
   ;;
 2)
   bash profiles/pmc_r03.sh $T veach showcase mc
@@ -30,9 +30,9 @@ case $PART in
   for sc in cornellbox_guided sun_sky; do
     python bench.py --scene $sc --steps 2 --warmup 1 --no-cpu-baseline >> gpurun_out/${T}_bench_other_configs.json 2>> gpurun_out/${T}_bench.err
   done
-  python bench.py --scene PointInstancedMedCity --width 3840 --height 2160 --spp-per-step 64 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${T}_bench_medcity_3840x2160.json 2>> gpurun_out/${T}_bench.err
+  python bench.py --scene PointInstancedMedCity --width 3840 --height 2160 --spp-per-step 128 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${T}_bench_medcity_3840x2160.json 2>> gpurun_out/${T}_bench.err
   stats bench_default
-  stats stress --scene stress --spp-per-step 64 --steps 2 --warmup 1
+  stats stress --scene stress --spp-per-step 256 --steps 2 --warmup 1
   ;;
 3)
   python bench_kernels.py > gpurun_out/${T}_kernel_probe.json 2> gpurun_out/${T}_kernel_probe.err

@@ -6,11 +6,11 @@ T=$1; shift; R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 KEYS=()
 for W in "$@"; do
   case $W in
-    stress)   A="--scene stress --spp-per-step 64 --steps 2 --warmup 1"; K="stress 1920x1080 64spp";;
-    cb)       A="--steps 2 --warmup 1"; K="cornellbox 1920x1080 256spp";;
-    veach)    A="--scene veach_mis --steps 2 --warmup 1"; K="veach_mis 1920x1080 256spp";;
-    showcase) A="--scene openpbr_showcase --steps 2 --warmup 1"; K="openpbr_showcase 1920x1080 256spp";;
-    mc)       A="--scene PointInstancedMedCity --width 3840 --height 2160 --spp-per-step 64 --steps 2 --warmup 1"; K="PointInstancedMedCity 3840x2160 64spp";;
+    stress)   A="--scene stress --spp-per-step 256 --steps 2 --warmup 1"; K="stress 1920x1080 256spp";;
+    cb)       A="--steps 2 --warmup 1"; K="cornellbox 1920x1080 512spp";;
+    veach)    A="--scene veach_mis --steps 2 --warmup 1"; K="veach_mis 1920x1080 512spp";;
+    showcase) A="--scene openpbr_showcase --steps 2 --warmup 1"; K="openpbr_showcase 1920x1080 512spp";;
+    mc)       A="--scene PointInstancedMedCity --width 3840 --height 2160 --spp-per-step 128 --steps 2 --warmup 1"; K="PointInstancedMedCity 3840x2160 128spp";;
   esac
   bash profiles/run_pmc_r02.sh ${T}$W bench.py --no-cpu-baseline $A > gpurun_out/${T}${W}_passes.log 2>&1
   python profiles/summarize_pmc.py ${T}$W > gpurun_out/${T}_pmc_$W.json
