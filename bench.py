@@ -152,8 +152,8 @@ def main():
 
     # the job's RayStats: all eight counters (stats.rs:128-147), one all_reduce
     all_stats = crt.shard.reduce_ray_stats(st, dist, coll)
-    names = [f for f, _t in st._fields_]
-    rays = [all_stats[names.index(f)] for f in ("closest_hit", "shadow_rays", "camera_rays", "vertices")]
+    stat_names = [f for f, _t in st._fields_]
+    rays = [all_stats[stat_names.index(f)] for f in ("closest_hit", "shadow_rays", "camera_rays", "vertices")]
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -270,7 +270,7 @@ def main():
             "shadow_rays": rays[1],
             "camera_rays": rays[2],
             "mean_path_length": round(rays[3] / max(rays[2], 1), 3),
-            "ray_stats": dict(zip(names, all_stats)),
+            "ray_stats": dict(zip(stat_names, all_stats)),
             "seconds": round(elapsed, 4),
             "spp_per_second": round(args.steps * spp_step / elapsed, 2),
             # the second half of BASELINE's metric: wall clock to the configuration's target spp (configs[1]: 1024) at this rate

@@ -37,6 +37,11 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
+    # the job's RayStats: all eight counters under their own names (a round-3 line carried them under the kernels' names)
+    rs = d["config"]["ray_stats"]
+    assert list(rs) == ["camera_rays", "closest_hit", "shadow_rays", "vertices", "rr_tested", "rr_killed", "ended_escaped", "ended_depth"]
+    assert rs["closest_hit"] == d["config"]["closest_hit"] and rs["camera_rays"] == d["config"]["camera_rays"] == 192 * 108 * 4 * 2
+    assert c["host_affinity"] >= c["cores"]
     # rays are counted as the reference counts them (stats.rs:150-152)
     assert d["config"]["rays_total"] == d["config"]["closest_hit"] + d["config"]["shadow_rays"]
 
