@@ -175,6 +175,7 @@ def main():
     # 96 B each way + 160 B material record) over the HIP-event duration of its launches in the timed region.
     pipe = r.pipeline()
     fused = pipe["fused"]
+    lanes = r.lanes()
     ext, sh = r.render_samples_stats(0, spp_step, stream)  # stats build, same batch shape; not timed
     n_steps = max(args.steps, 1)
     alg = {"extend": ext.algorithmic_bytes(), "shadow": sh.algorithmic_bytes(), "shade": 352 * (st.vertices // n_steps)}
@@ -229,6 +230,10 @@ def main():
                    "k_shade": "k_shade (one path vertex per live path: emission, NEE sample, OpenPBR sample, roulette, compaction)",
                    "k_shadow": "k_shadow (BVH4 any-hit traversal of one bounce's shadow rays, %d workgroups per CU)" % waves}.get(dominant),
         "pipeline": "fused" if fused else ("per-stage, %d workgroups per CU in the traversal kernels" % waves),
+        # a batch runs as `lanes` sub-batches on their own streams: their launches OVERLAP, so a launch's own duration
+        # (avg_launch_ms, HIP events on its stream) includes the time it shares the chip, and the per-step sum of the
+        # kernels' times (kernel_ms) exceeds ms_per_step by that overlap
+        "lanes": lanes,
         "kernel_source_hash": kernel_source_hash(),
         "traversal_bytes_per_ray": round(ext.algorithmic_bytes() / max(int(ext.rays), 1), 1),
         "shadow_bytes_per_ray": round(sh.algorithmic_bytes() / max(int(sh.rays), 1), 1) if int(sh.rays) else None,

@@ -160,7 +160,7 @@ ABI_SYMBOLS = [
     "crt_renderer_pixel_count", "crt_renderer_pixel_indices", "crt_render_samples", "crt_film_resolve",
     "crt_film_read", "crt_film_clear", "crt_renderer_active_pixels", "crt_renderer_sample_counts", "crt_render_stats", "crt_renderer_profile", "crt_renderer_profile_read",
     "crt_render_samples_stats", "crt_version", "crt_last_error", "crt_device_info",
-    "crt_scene_primitive_extents", "crt_scene_traversal_error", "crt_thread_release", "crt_renderer_shade_class_stats", "crt_renderer_pipeline", "crt_scene_image_check",
+    "crt_scene_primitive_extents", "crt_scene_traversal_error", "crt_thread_release", "crt_renderer_shade_class_stats", "crt_renderer_pipeline", "crt_renderer_lanes", "crt_scene_image_check",
 ]
 
 _lib = None
@@ -241,6 +241,9 @@ def lib():
         L.crt_renderer_active_pixels.argtypes = [vp]
         L.crt_renderer_sample_counts.argtypes = [vp, up]
         L.crt_renderer_profile.argtypes = [vp, C.c_int]
+        if hasattr(L, "crt_renderer_lanes"):  # absent from older A/B variant libraries
+            L.crt_renderer_lanes.argtypes = [vp]
+            L.crt_renderer_lanes.restype = C.c_int
         if hasattr(L, "crt_renderer_pipeline"):  # absent from older A/B variant libraries
             L.crt_renderer_pipeline.argtypes = [vp, C.POINTER(C.c_uint32)]
         if hasattr(L, "crt_renderer_shade_class_stats"):  # absent from older A/B variant libraries
@@ -695,6 +698,10 @@ class Renderer:
         out = (C.c_uint32 * 3)()
         _check(lib().crt_renderer_pipeline(self.h, out), "crt_renderer_pipeline")
         return dict(fused=bool(out[0]), wide=bool(out[1]), grid=int(out[2]))
+
+    def lanes(self):
+        """Sub-batches (own buffers, own HIP stream) the last batch ran as (crt.h, crt_renderer_lanes)."""
+        return int(lib().crt_renderer_lanes(self.h)) if hasattr(lib(), "crt_renderer_lanes") else 1
 
     def profile(self, enable=True):
         _check(lib().crt_renderer_profile(self.h, 1 if enable else 0), "crt_renderer_profile")

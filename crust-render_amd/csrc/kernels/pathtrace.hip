@@ -1125,14 +1125,30 @@ struct Renderer {
   std::shared_ptr<Scene> scene;
   Params P{};
   std::vector<uint32_t> pixels;  // owned pixels (linear buffer index), tile order
-  size_t cap_slots = 0;          // path slots (segment capacity x segments) the buffers are sized for
-  char *blob = nullptr;
-  size_t blob_bytes = 0;
-  PathSoA S[2]{};
-  HitSoA H{};
-  ShadowSoA Q{};
-  Counters *C = nullptr;
-  float4 *staging = nullptr;
+  // One wavefront batch's buffers: path state (two buffers), hit records, shadow queue, staging film, queue counters.
+  // LANES: a batch of n samples runs as up to kMaxLanes sub-batches of n / lanes consecutive samples, each with its own
+  // buffers and counters on its own HIP stream, so the launches of one sub-batch overlap the other's — the ramp-up and
+  // the drain of a launch (workgroups of its last round finishing one by one) are filled by the other lane's work, and a
+  // traversal launch (latency and issue bound) runs beside a shade launch (the one that moves bytes). The film fold
+  // stays on the caller's stream, lane after lane, so samples are summed in the same order as in one batch: bits unchanged.
+  struct Lane {
+    size_t cap_slots = 0;          // path slots (segment capacity x segments) the buffers are sized for
+    char *blob = nullptr;
+    size_t blob_bytes = 0;
+    PathSoA S[2]{};
+    HitSoA H{};
+    ShadowSoA Q{};
+    Counters *C = nullptr;
+    float4 *staging = nullptr;
+    hipStream_t stream = nullptr;  // lanes 1.. only (lane 0 runs on the caller's stream)
+    hipEvent_t done = nullptr;
+  };
+  static constexpr int kMaxLanes = 4;
+  Lane lanes[kMaxLanes];
+  int n_lanes = 4;               // CRT_LANES; a batch is split only while every lane keeps lane_min_paths paths
+  int last_lanes = 1;            // of the last batch (crt_renderer_lanes)
+  size_t lane_min_paths = (size_t)96 << 20;
+  hipEvent_t ev_start = nullptr;
   float4 *film = nullptr;
   CrtMaterial *d_materials = nullptr;
   uint8_t *d_mat_class = nullptr;  // material_class() per record of d_materials
@@ -1170,8 +1186,14 @@ struct Renderer {
 
   ~Renderer() {
     drain_events();
-    if (blob) (void)hipFree(blob);
-    if (C) (void)hipFree(C);
+    for (Lane &B : lanes) {
+      if (B.stream) (void)hipStreamSynchronize(B.stream);  // nothing of a lane may be in flight when its buffers go
+      if (B.blob) (void)hipFree(B.blob);
+      if (B.C) (void)hipFree(B.C);
+      if (B.stream) (void)hipStreamDestroy(B.stream);
+      if (B.done) (void)hipEventDestroy(B.done);
+    }
+    if (ev_start) (void)hipEventDestroy(ev_start);
     if (film) (void)hipFree(film);
     if (d_materials) (void)hipFree(d_materials);
     if (d_mat_class) (void)hipFree(d_mat_class);
@@ -1213,7 +1235,13 @@ struct Renderer {
     return g > kMaxGrid ? kMaxGrid : g;
   }
 
-  int ensure_buffers(size_t slots) {  // slots = segment capacity x segments of the batch about to run
+  int ensure_buffers(Lane &B, size_t slots) {  // slots = segment capacity x segments of the batch about to run
+    size_t &cap_slots = B.cap_slots, &blob_bytes = B.blob_bytes;
+    char *&blob = B.blob;
+    PathSoA (&S)[2] = B.S;
+    HitSoA &H = B.H;
+    ShadowSoA &Q = B.Q;
+    float4 *&staging = B.staging;
     if (slots <= cap_slots && blob) return CRT_OK;
     if (blob) { (void)hipFree(blob); blob = nullptr; }
     const size_t total = slots, cap = slots;  // shadow queue and staging film: one slot per path
@@ -1255,6 +1283,49 @@ struct Renderer {
     if (n_samples == 0) return CRT_OK;
     if (n_samples > 0xffffu) return CRT_ERR_BAD_ARG;
     last_stream = st;
+    // how many lanes: one for the stats build and adaptive stopping (the active list changes between batches) and for
+    // batches too small to fill the chip twice over
+    int L = n_lanes;
+    const size_t total = (size_t)P.n_pix * n_samples;
+    if (d_tstats || variance_threshold > 0.0f) L = 1;
+    while (L > 1 && (total / L < lane_min_paths || n_samples < (uint32_t)L)) L--;
+    last_lanes = L < 1 ? 1 : L;
+    if (L <= 1) return render_lane(lanes[0], sample_begin, n_samples, st, d_tstats, true);
+    if (!ev_start && !CRT_HIP_OK(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming))) return CRT_ERR_NO_DEVICE;
+    for (int l = 1; l < L; l++) {
+      Lane &B = lanes[l];
+      if (!B.stream && !CRT_HIP_OK(hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking))) return CRT_ERR_NO_DEVICE;
+      if (!B.done && !CRT_HIP_OK(hipEventCreateWithFlags(&B.done, hipEventDisableTiming))) return CRT_ERR_NO_DEVICE;
+    }
+    // every lane starts behind what the caller's stream has queued (the previous batch's film fold reads the staging
+    // films this batch overwrites); lane 0 IS the caller's stream
+    if (!CRT_HIP_OK(hipEventRecord(ev_start, st))) return CRT_ERR_NO_DEVICE;
+    uint32_t begin[kMaxLanes], count[kMaxLanes];
+    for (int l = 0; l < L; l++) {
+      count[l] = n_samples / L + ((uint32_t)l < n_samples % L ? 1u : 0u);
+      begin[l] = l == 0 ? sample_begin : begin[l - 1] + count[l - 1];
+    }
+    // the lanes on their own streams first, lane 0 on the caller's last: its launches then queue behind nothing of ours
+    for (int l = L - 1; l >= 0; l--) {
+      hipStream_t ls = l == 0 ? st : lanes[l].stream;
+      if (l > 0 && !CRT_HIP_OK(hipStreamWaitEvent(ls, ev_start, 0))) return CRT_ERR_NO_DEVICE;
+      const int rc = render_lane(lanes[l], begin[l], count[l], ls, nullptr, false);
+      if (rc != CRT_OK) return rc;
+      if (l > 0 && !CRT_HIP_OK(hipEventRecord(lanes[l].done, ls))) return CRT_ERR_NO_DEVICE;
+    }
+    // the film fold: lane after lane on the caller's stream = sample order
+    for (int l = 0; l < L; l++) {
+      if (l > 0 && !CRT_HIP_OK(hipStreamWaitEvent(st, lanes[l].done, 0))) return CRT_ERR_NO_DEVICE;
+      timed(3, st, [&] { hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(kBlock), 0, st, lanes[l].staging, P.n_pix, count[l], film); });
+    }
+    return CRT_HIP_OK(hipGetLastError()) ? CRT_OK : CRT_ERR_NO_DEVICE;
+  }
+
+  int render_lane(Lane &B, uint32_t sample_begin, uint32_t n_samples, hipStream_t st, CrtTravStats *d_tstats, bool fold_here) {
+    PathSoA (&S)[2] = B.S;
+    HitSoA &H = B.H;
+    ShadowSoA &Q = B.Q;
+    Counters *C = B.C;
     const bool adaptive = variance_threshold > 0.0f;
     if (adaptive && n_act == 0) return CRT_OK;  // every pixel has stopped
     Params p = P;
@@ -1268,15 +1339,17 @@ struct Renderer {
       if (P.has_inf_lights) fused = false;  // no fused instance for lights at infinity (see k_path)
       grid = batch_grid(total, fused);
       p.seg_cap = (uint32_t)(((total + (size_t)grid * kBlock - 1) / ((size_t)grid * kBlock)) * kBlock);
-      const int rc = ensure_buffers((size_t)p.seg_cap * grid);  // >= total: the staging film's (sample, active pixel) slots too
+      const int rc = ensure_buffers(B, (size_t)p.seg_cap * grid);  // >= total: the staging film's (sample, active pixel) slots too
       if (rc != CRT_OK) return rc;
     }
+    float4 *staging = B.staging;
     const bool wide = !fused && this->wide;  // per-stage launches take the scene's preferred traversal kernels
     // camera paths as 16-byte records: per-stage launches of an UNLIT scene, pinhole camera, static scene
     // (CRT_CAM_COMPACT=0: A/B, tests)
     p.cam_compact = (CRT_CAM_COMPACT_BUILD && !fused && cam_compact_ok && P.n_lights == 0 && !(P.camera.lens_radius > 0.0f) && !P.has_motion) ? 1u : 0u;
     // the film fold: plain sum, or with the luminance statistics and the stopping rule, then the new active list
     auto fold = [&]() -> int {
+      if (!fold_here) return CRT_HIP_OK(hipGetLastError()) ? CRT_OK : CRT_ERR_NO_DEVICE;  // the caller folds the lanes in order
       if (!adaptive) {
         timed(3, st, [&] { hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(kBlock), 0, st, staging, P.n_pix, n_samples, film); });
         return CRT_HIP_OK(hipGetLastError()) ? CRT_OK : CRT_ERR_NO_DEVICE;
@@ -1449,7 +1522,8 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
          CRT_HIP_OK(hipMalloc(&r.d_state, (size_t)P.n_pix * 4)) && CRT_HIP_OK(hipMemset(r.d_state, 0, (size_t)P.n_pix * 4)) &&
          CRT_HIP_OK(hipMalloc(&r.d_active, (size_t)P.n_pix * 4)) && CRT_HIP_OK(hipMalloc(&r.d_count, 4));
   }
-  ok = ok && CRT_HIP_OK(hipMalloc(&r.C, sizeof(Counters))) && CRT_HIP_OK(hipMemset(r.C, 0, sizeof(Counters)));
+  for (Renderer::Lane &B : r.lanes)
+    ok = ok && CRT_HIP_OK(hipMalloc(&B.C, sizeof(Counters))) && CRT_HIP_OK(hipMemset(B.C, 0, sizeof(Counters)));
   ok = ok && CRT_HIP_OK(hipMalloc(&r.film, (size_t)P.n_pix * 16)) && CRT_HIP_OK(hipMemset(r.film, 0, (size_t)P.n_pix * 16));
   ok = ok && CRT_HIP_OK(hipMalloc(&r.d_pixels, (size_t)P.n_pix * 4)) &&
        CRT_HIP_OK(hipMemcpy(r.d_pixels, r.pixels.data(), (size_t)P.n_pix * 4, hipMemcpyHostToDevice));
@@ -1539,6 +1613,8 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
   if (const char *e = getenv("CRT_CAM_COMPACT")) r.cam_compact_ok = atoi(e) != 0;
   if (const char *e = getenv("CRT_NOCLASSIFY_FROM")) r.noclassify_from = atoi(e);
   if (const char *e = getenv("CRT_TAIL_FROM")) r.tail_from = atoi(e);
+  if (const char *e = getenv("CRT_LANES")) { const int n = atoi(e); r.n_lanes = n < 1 ? 1 : (n > Renderer::kMaxLanes ? Renderer::kMaxLanes : n); }
+  if (const char *e = getenv("CRT_LANE_MIN_PATHS")) r.lane_min_paths = (size_t)strtoull(e, nullptr, 10);
   if (const char *e = getenv("CRT_SHADE_WIDE")) r.shade_wide = atoi(e) != 0 ? 1 : 0;
   if (const char *e = getenv("CRT_FUSED")) r.force_fused = atoi(e) != 0 ? 1 : 0;
   if (const char *e = getenv("CRT_STAGE_MIN_PATHS")) r.stage_min_paths = (size_t)strtoull(e, nullptr, 10);
@@ -1605,7 +1681,7 @@ int crt_film_read(CrtRenderer *r, float *host_rgb) {
 int crt_film_clear(CrtRenderer *r, void *stream) {
   if (!r) return CRT_ERR_BAD_ARG;
   bool ok = CRT_HIP_OK(hipMemsetAsync(r->r.film, 0, (size_t)r->r.P.n_pix * 16, (hipStream_t)stream));
-  ok = ok && CRT_HIP_OK(hipMemsetAsync(r->r.C, 0, sizeof(Counters), (hipStream_t)stream));
+  for (Renderer::Lane &B : r->r.lanes) ok = ok && CRT_HIP_OK(hipMemsetAsync(B.C, 0, sizeof(Counters), (hipStream_t)stream));
   if (ok && r->r.d_state) {
     ok = CRT_HIP_OK(hipMemsetAsync(r->r.d_state, 0, (size_t)r->r.P.n_pix * 4, (hipStream_t)stream)) &&
          CRT_HIP_OK(hipMemsetAsync(r->r.d_pstats, 0, (size_t)r->r.P.n_pix * sizeof(PixelStats), (hipStream_t)stream));
@@ -1618,11 +1694,17 @@ int crt_render_stats(CrtRenderer *r, CrtRayStats *out) {
   struct { uint32_t err, pad; unsigned long long stats[8]; } h;  // the head of Counters
   static_assert(offsetof(Counters, seg) == sizeof h, "Counters head layout");
   if (!CRT_HIP_OK(hipStreamSynchronize(r->r.last_stream))) return CRT_ERR_NO_DEVICE;
-  if (!CRT_HIP_OK(hipMemcpy(&h, r->r.C, sizeof h, hipMemcpyDeviceToHost))) return CRT_ERR_NO_DEVICE;
-  out->camera_rays = h.stats[0]; out->closest_hit = h.stats[1]; out->shadow_rays = h.stats[2];
-  out->vertices = h.stats[3]; out->rr_tested = h.stats[4]; out->rr_killed = h.stats[5];
-  out->ended_escaped = h.stats[6]; out->ended_depth = h.stats[7];
-  return h.err ? CRT_ERR_STACK : CRT_OK;
+  unsigned long long sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t err = 0;
+  for (const Renderer::Lane &B : r->r.lanes) {  // the lanes of a batch count their own rays
+    if (!CRT_HIP_OK(hipMemcpy(&h, B.C, sizeof h, hipMemcpyDeviceToHost))) return CRT_ERR_NO_DEVICE;
+    for (int k = 0; k < 8; k++) sum[k] += h.stats[k];
+    err |= h.err;
+  }
+  out->camera_rays = sum[0]; out->closest_hit = sum[1]; out->shadow_rays = sum[2];
+  out->vertices = sum[3]; out->rr_tested = sum[4]; out->rr_killed = sum[5];
+  out->ended_escaped = sum[6]; out->ended_depth = sum[7];
+  return err ? CRT_ERR_STACK : CRT_OK;
 }
 size_t crt_renderer_active_pixels(const CrtRenderer *r) { return r ? (r->r.variance_threshold > 0.0f ? r->r.n_act : r->r.P.n_pix) : 0; }
 int crt_renderer_sample_counts(CrtRenderer *r, uint32_t *host_out) {
@@ -1639,13 +1721,17 @@ int crt_renderer_shade_class_stats(CrtRenderer *r, int enable, uint64_t out_wave
   if (out_waves && out_lanes) {
     unsigned long long h[8];
     if (!CRT_HIP_OK(hipStreamSynchronize(R.last_stream))) return CRT_ERR_NO_DEVICE;
-    if (!CRT_HIP_OK(hipMemcpy(h, R.C->cls_waves, sizeof h, hipMemcpyDeviceToHost))) return CRT_ERR_NO_DEVICE;
-    if (!CRT_HIP_OK(hipMemset(R.C->cls_waves, 0, sizeof h))) return CRT_ERR_NO_DEVICE;
-    for (int c = 0; c < 4; c++) { out_waves[c] = h[c]; out_lanes[c] = h[4 + c]; }
+    for (int c = 0; c < 4; c++) out_waves[c] = out_lanes[c] = 0;
+    for (Renderer::Lane &B : R.lanes) {
+      if (!CRT_HIP_OK(hipMemcpy(h, B.C->cls_waves, sizeof h, hipMemcpyDeviceToHost))) return CRT_ERR_NO_DEVICE;
+      if (!CRT_HIP_OK(hipMemset(B.C->cls_waves, 0, sizeof h))) return CRT_ERR_NO_DEVICE;
+      for (int c = 0; c < 4; c++) { out_waves[c] += h[c]; out_lanes[c] += h[4 + c]; }
+    }
   }
   if (enable >= 0) R.P.class_stats = enable ? 1u : 0u;
   return CRT_OK;
 }
+int crt_renderer_lanes(const CrtRenderer *r) { return r ? r->r.last_lanes : 0; }
 int crt_renderer_pipeline(const CrtRenderer *r, uint32_t out[3]) {
   if (!r || !out) return CRT_ERR_BAD_ARG;
   out[0] = r->r.fused ? 1u : 0u;

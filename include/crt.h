@@ -283,6 +283,12 @@ int crt_renderer_shade_class_stats(CrtRenderer *r, int enable, uint64_t out_wave
  * scenes and the fused kernel otherwise (instance-heavy or sphere-only scenes, small batches). Environment CRT_FUSED /
  * CRT_WIDE / CRT_STAGE_MIN_PATHS / CRT_GRID_MULT override. */
 int crt_renderer_pipeline(const CrtRenderer *r, uint32_t out[3]);
+/* Lanes of the last batch rendered (1 before the first): a batch of at least 2 x 96 Mi paths runs as 2 (CRT_LANES, up to
+ * 4) sub-batches of consecutive samples, each with its own buffers and counters on its own HIP stream, so one
+ * sub-batch's launches overlap the other's; the film fold stays on the caller's stream, lane after lane — samples are
+ * summed in the order of one batch and the image bits do not depend on the lane count (tests/test_gpu_render.py).
+ * No reference counterpart (the reference renders tiles on Rayon workers, tracer.rs:424-459). */
+int crt_renderer_lanes(const CrtRenderer *r);
 /* Live HIP-event timing of the kernels launched by crt_render_samples since the last reset, by class:
  * 0 = extend (closest-hit traversal) — or, in the fused pipeline, the path-loop kernel that runs generate, extend,
  * shade and shadow of a whole batch in one launch — 1 = shade, 2 = shadow (occlusion traversal), 3 = other.

@@ -69,7 +69,7 @@ def test_config2_cornellbox_1080p_depth32_one_bench_batch_whole_frame(crt):
 
 def test_config2_cornellbox_1080p_the_shipped_bench_batch(crt):
     """bench.py's default step since round 3: 512 spp of every pixel in ONE batch — 1 061.7 M paths, 174 GB of path state,
-    8 192 workgroup segments, 16-byte camera paths, the fused tail from bounce 12 — on 4 096 random pixels against the
+    8 192 workgroup segments in lanes on their own streams, 16-byte camera paths, the fused tail from bounce 12 — on 4 096 random pixels against the
     oracle (per-pixel independence makes any subset exact), and the ray total against the 256-spp whole-frame run's law:
     every camera ray is traced."""
     import torch
@@ -78,7 +78,8 @@ def test_config2_cornellbox_1080p_the_shipped_bench_batch(crt):
     st = r.stats()
     assert st.camera_rays == w * h * spp and st.closest_hit > st.camera_rays and st.shadow_rays == 0
     p = r.pipeline()
-    assert p["fused"] is False and p["wide"] is True and p["grid"] == 8192
+    # the batch runs as lanes (sub-batches of consecutive samples on their own streams): 8 192 segments in all
+    assert p["fused"] is False and p["wide"] is True and r.lanes() >= 2 and p["grid"] * r.lanes() == 8192
     idx = _subset(w * h, 4096, 5)
     opx, _ = ora_world.OracleRenderer(desc, crt.usda, max_depth=depth).render_pixels(idx, spp, forward=1)
     assert np.array_equal(r.image().reshape(-1, 3)[idx].view(np.uint32), opx.view(np.uint32))

@@ -258,6 +258,12 @@ def test_shade_class_partition_keeps_waves_pure_and_bits_unchanged(crt):
     ("cornellbox.usda", (160, 90, 8), {"CRT_FUSED": "0"}, {"CRT_NOCLASSIFY_FROM": "1"}),   # shade without its CLASSIFY pass
     ("cornellbox.usda", (160, 90, 8), {"CRT_FUSED": "0"}, {"CRT_HOT_PACKETS": "0"}),       # packets in builder order
     ("stress", (96, 54, 6), {}, {"CRT_POOL_STACK_RT": "6"}),                               # a large tree on the flat LDS split
+    # a batch as ONE lane against two / three lanes on their own streams (forced: these batches are far below the size
+    # from which the renderer splits on its own) — per-stage unlit, fused lit, fused instanced, 8 samples into 3 lanes: 3 + 3 + 2
+    ("cornellbox.usda", (160, 90, 8), {"CRT_FUSED": "0", "CRT_LANES": "1"}, {"CRT_LANES": "2", "CRT_LANE_MIN_PATHS": "1"}),
+    ("stress", (96, 54, 6), {"CRT_LANES": "1"}, {"CRT_LANES": "3", "CRT_LANE_MIN_PATHS": "1"}),
+    ("PointInstancedMedCity.usd", (96, 54, 6), {"CRT_LANES": "1"}, {"CRT_LANES": "4", "CRT_LANE_MIN_PATHS": "1"}),
+    ("veach_mis.usda", (160, 90, 8), {"CRT_FUSED": "0", "CRT_LANES": "1"}, {"CRT_LANES": "3", "CRT_LANE_MIN_PATHS": "1"}),
 ])
 def test_round3_knobs_change_no_bit(crt, scene, res, base_env, knob):
     """Round 3's layout and scheduling choices — deduplicated material table, 16-byte camera paths, hot-first packet order,
@@ -277,8 +283,10 @@ def test_round3_knobs_change_no_bit(crt, scene, res, base_env, knob):
     out = []
     for k, extra in enumerate(({}, knob)):
         path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "crt_knob%d.npy" % k)
-        res_ = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **base_env, **extra), capture_output=True,
-                              text=True, timeout=300)
+        env = dict(os.environ)
+        env.update(base_env)
+        env.update(extra)
+        res_ = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=300)
         assert res_.returncode == 0, res_.stderr[-2000:]
         out.append((np.load(path), json.loads(res_.stdout.strip().splitlines()[-1])))
     assert out[0][1] == out[1][1], (knob, out[0][1], out[1][1])
