@@ -14,6 +14,9 @@ resident in HBM before the timed region starts. 1024 spp is 2 such steps; the de
 Metric (stats.rs:150-152): Mray/s = (closest_hit + shadow_rays) / render seconds / 1e6, summed
 over all ranks; the timed region is K steps bracketed by barrier + synchronize, MAX over ranks.
 
+A batch runs as up to four LANES (crt.h, crt_renderer_lanes): sub-batches of consecutive samples on their own HIP
+streams whose launches overlap; the film is folded in sample order. config/roofline.lanes reports the count.
+
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL). The frame's 16x16 tiles are dealt round-robin
 to the ranks; each rank traces `--spp-per-step * N` samples of its own tiles per step, so per-GPU work per step is
 fixed as N grows ("weak": N GPUs advance the frame N times as many spp per step). Tile ownership is disjoint, so
@@ -189,7 +192,9 @@ def main():
         k_ms, k_n = prof[cls]["ms"], prof[cls]["launches"]
         if k_n == 0 or k_ms <= 0:
             continue
-        kernels[names[cls]] = _roofline_entry(names[cls], per_step * n_steps / k_n, k_ms, k_n, n_steps, workload_key, world)
+        # (the committed PMC passes are taken with CRT_LANES=1: their per-launch figures are a whole batch's launch)
+        kernels[names[cls]] = _roofline_entry(names[cls], per_step * n_steps / k_n, k_ms, k_n, n_steps, workload_key, world,
+                                              traffic_scale=1.0 / lanes)
     dominant = max(kernels, key=lambda k: kernels[k]["total_ms"]) if kernels else None
     # the other pipeline on the same workload, 2 untimed steps: per-stage split of a fused step / the fused kernel's time.
     # The timed renderer's buffers (87 GB at the default shape) are released first.
@@ -197,6 +202,36 @@ def main():
     n_pix = r.n_pix
     del r
     stage = other = None
+    # With lanes the launches of the timed region overlap: a launch's own duration then includes the time it shares the
+    # chip with the other lanes' launches, and says little about the kernel. The same batch once more as ONE lane
+    # (CRT_LANES=1, 2 untimed steps): every kernel alone on the chip, the durations the fractions below are priced on.
+    serial = None
+    if lanes > 1:
+        saved_l = os.environ.get("CRT_LANES")
+        try:
+            os.environ["CRT_LANES"] = "1"
+            r1, _ = crt.load_usda(path, args.width, args.height, args.depth, rank=rank, world=world)
+            r1.render_samples(0, spp_step, stream)
+            torch.cuda.synchronize()
+            r1.profile(True)
+            for k in range(2):
+                r1.render_samples(k * spp_step, spp_step, stream)
+            torch.cuda.synchronize()
+            p1 = r1.profile_read()
+            serial = {}
+            for cls, per_step in alg.items():
+                if p1[cls]["launches"] and p1[cls]["ms"] > 0:
+                    serial[names[cls]] = _roofline_entry(names[cls], per_step * 2 / p1[cls]["launches"], p1[cls]["ms"], p1[cls]["launches"], 2,
+                                                         workload_key, world)
+            serial_ms = {k: round(v["ms"] / 2, 3) for k, v in p1.items()}
+            del r1
+        except crt.CrtError as e:
+            serial = None
+        finally:
+            if saved_l is None:
+                os.environ.pop("CRT_LANES", None)
+            else:
+                os.environ["CRT_LANES"] = saved_l
     saved = {k: os.environ.get(k) for k in ("CRT_FUSED", "CRT_WIDE")}
     try:
         os.environ["CRT_FUSED"] = "0" if fused else "1"
@@ -224,6 +259,16 @@ def main():
             else:
                 os.environ[k] = v
     roofline = dict(kernels[dominant]) if dominant else {}
+    if serial and dominant in serial:
+        # headline figures on the un-overlapped launch; what the timed region's HIP events measured stays beside them
+        timed = {k: roofline.get(k) for k in ("achieved", "frac", "avg_launch_ms", "launches", "launches_per_step", "total_ms",
+                                              "bytes_per_launch", "hbm_measured_frac", "valu_issue_frac", "bound", "peak")}
+        roofline = dict(serial[dominant])
+        roofline["timing"] = ("2 untimed steps as ONE lane (CRT_LANES=1) after the timed region: every launch alone on the chip. "
+                              "In the timed region the batch runs as %d lanes whose launches overlap (timed_region: a launch's own "
+                              "start-to-end time on its stream, which includes the time it shares the chip)" % lanes)
+        roofline["timed_region"] = timed
+        roofline["serial_kernel_ms_per_step"] = serial_ms
     roofline.update({
         "kernel": {"k_path": "k_path (one launch per batch: generate + BVH4 traversal + shading + shadow per queue segment)",
                    "k_extend": "k_extend (BVH4 closest-hit traversal of one bounce's rays, %d workgroups per CU)" % waves,
@@ -239,7 +284,7 @@ def main():
         "shadow_bytes_per_ray": round(sh.algorithmic_bytes() / max(int(sh.rays), 1), 1) if int(sh.rays) else None,
         "shading_bytes_per_vertex": 352,
         "kernel_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
-        "kernels": {k: v for k, v in kernels.items() if k != dominant},  # the other stages of the per-stage pipeline
+        "kernels": {k: v for k, v in (serial if serial else kernels).items() if k != dominant},  # the other stages of the per-stage pipeline
         "unfused_stage_ms_per_step": stage,
         "other_pipeline": other,
     })
@@ -294,7 +339,7 @@ def main():
 L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md: L2 aggregate ~34.5 TB/s (eight XCDs x 4 MiB)
 
 
-def _roofline_entry(kernel, bytes_per_launch, k_ms, k_n, n_steps, workload_key, world):
+def _roofline_entry(kernel, bytes_per_launch, k_ms, k_n, n_steps, workload_key, world, traffic_scale=1):
     """One kernel's roofline figures. `achieved` is the contract's definition — ALGORITHMIC bytes per launch over the
     average launch duration (HIP events). `bound` / `peak` / `frac` name the tier that actually serves those bytes:
     with the committed PMC passes of this build at hand (profiles/r03_pmc_bench.json, keyed by kernel source hash), a
@@ -307,10 +352,11 @@ def _roofline_entry(kernel, bytes_per_launch, k_ms, k_n, n_steps, workload_key, 
     pmc, note = _pmc_for(workload_key, kernel) if world == 1 else (None, "N > 1")
     traffic = hbm_frac = l2_hit = valu_issue = wave = None
     if pmc:
-        traffic = int(pmc["ea_dram_read_bytes_per_launch"] + pmc["ea_dram_write_bytes_per_launch"])
+        # the PMC passes profile whole-batch launches (CRT_LANES=1); a lane's launch covers `traffic_scale` of one
+        traffic = int((pmc["ea_dram_read_bytes_per_launch"] + pmc["ea_dram_write_bytes_per_launch"]) * traffic_scale)
         hbm_frac = round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4)
         l2_hit = round(pmc["l2_hit_rate"], 4)
-        valu_issue = round(pmc["valu_insts_per_launch"] / avg_s / VALU_ISSUE_PEAK, 4)
+        valu_issue = round(pmc["valu_insts_per_launch"] * traffic_scale / avg_s / VALU_ISSUE_PEAK, 4)
         rnd = lambda x: None if x is None else round(x, 4)
         wave = {"issuing": rnd(pmc.get("inst_active_frac")), "waiting_on_memory": rnd(pmc.get("wait_any_frac")),
                 "waiting_for_instructions": rnd(pmc.get("wait_inst_frac"))}

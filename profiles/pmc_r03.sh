@@ -3,6 +3,7 @@
 # then the per-kernel summary bench.py reads (profiles/r03_pmc_bench.json, written HERE on the profiled build).
 #   bash profiles/pmc_r03.sh <tag> stress|cb|veach|showcase|mc ...
 T=$1; shift; R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+export CRT_LANES=1   # whole-batch launches: per-launch counters are then one batch's launch (bench.py scales them per lane)
 KEYS=()
 for W in "$@"; do
   case $W in
