@@ -232,9 +232,10 @@ def main():
                 os.environ.pop("CRT_LANES", None)
             else:
                 os.environ["CRT_LANES"] = saved_l
-    saved = {k: os.environ.get(k) for k in ("CRT_FUSED", "CRT_WIDE")}
+    saved = {k: os.environ.get(k) for k in ("CRT_FUSED", "CRT_WIDE", "CRT_LANES")}
     try:
         os.environ["CRT_FUSED"] = "0" if fused else "1"
+        os.environ["CRT_LANES"] = "1"  # one lane: the other pipeline's launches alone on the chip, comparable with `serial`
         r2, _ = crt.load_usda(path, args.width, args.height, args.depth, rank=rank, world=world)
         r2.render_samples(0, spp_step, stream)
         torch.cuda.synchronize()
