@@ -1242,7 +1242,9 @@ struct Renderer {
     HitSoA &H = B.H;
     ShadowSoA &Q = B.Q;
     float4 *&staging = B.staging;
-    if (slots <= cap_slots && blob) return CRT_OK;
+    // grow only — except that a lane of a multi-lane batch gives back a buffer sized for a whole batch (a single-lane
+    // call before it, e.g. the stats pass): four lanes next to one whole-batch buffer would not fit the HBM
+    if (slots <= cap_slots && blob && !(last_lanes > 1 && cap_slots > slots + slots / 2)) return CRT_OK;
     if (blob) { (void)hipFree(blob); blob = nullptr; }
     const size_t total = slots, cap = slots;  // shadow queue and staging film: one slot per path
     const size_t bcap = cap * kBins;      // path and hit planes: one sub-segment per (workgroup, direction bin)
@@ -1290,6 +1292,15 @@ struct Renderer {
     if (d_tstats || variance_threshold > 0.0f) L = 1;
     while (L > 1 && (total / L < lane_min_paths || n_samples < (uint32_t)L)) L--;
     last_lanes = L < 1 ? 1 : L;
+    // lanes this batch does not use give their buffers back first: a whole batch in lane 0 next to the quarter batches of
+    // an earlier call's other lanes would not fit (the stats pass behind a four-lane batch of a lit scene: 259 + 195 GB)
+    for (int l = L < 1 ? 1 : L; l < kMaxLanes; l++) {
+      Lane &B = lanes[l];
+      if (!B.blob) continue;
+      if (B.stream) (void)hipStreamSynchronize(B.stream);
+      (void)hipFree(B.blob);
+      B.blob = nullptr; B.cap_slots = 0; B.blob_bytes = 0;
+    }
     if (L <= 1) return render_lane(lanes[0], sample_begin, n_samples, st, d_tstats, true);
     if (!ev_start && !CRT_HIP_OK(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming))) return CRT_ERR_NO_DEVICE;
     for (int l = 1; l < L; l++) {

@@ -291,3 +291,28 @@ def test_round3_knobs_change_no_bit(crt, scene, res, base_env, knob):
         out.append((np.load(path), json.loads(res_.stdout.strip().splitlines()[-1])))
     assert out[0][1] == out[1][1], (knob, out[0][1], out[1][1])
     assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32)), knob
+
+
+def test_lanes_and_single_lane_batches_alternate_within_one_renderer(crt, monkeypatch):
+    """A renderer that runs a batch as lanes, then a single-lane batch (the stats pass), then lanes again: the lanes a
+    batch does not use give their buffers back and a whole-batch buffer is not kept next to lanes (Renderer::render,
+    ensure_buffers) — and the image is the one a single-lane renderer produces for the same samples."""
+    import torch
+    monkeypatch.setenv("CRT_LANES", "3")
+    monkeypatch.setenv("CRT_LANE_MIN_PATHS", "1")
+    r, desc = crt.load_usda(crt.scene_path("veach_mis"), 96, 54, 8)
+    r.render_samples(0, 6)
+    assert r.lanes() == 3
+    ext, sh = r.render_samples_stats(6, 6)   # single lane by construction
+    assert r.lanes() == 1 and ext.rays > 0 and sh.rays > 0
+    r.render_samples(12, 5)
+    assert r.lanes() == 3
+    torch.cuda.synchronize()
+    img, st = r.image(), r.stats()
+    monkeypatch.setenv("CRT_LANES", "1")
+    r1, _ = crt.load_usda(crt.scene_path("veach_mis"), 96, 54, 8)
+    r1.render_samples(0, 6); r1.render_samples(6, 6); r1.render_samples(12, 5)
+    torch.cuda.synchronize()
+    assert np.array_equal(img.view(np.uint32), r1.image().view(np.uint32))
+    st1 = r1.stats()
+    assert (st.closest_hit, st.shadow_rays, st.vertices) == (st1.closest_hit, st1.shadow_rays, st1.vertices)
