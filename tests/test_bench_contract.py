@@ -120,3 +120,29 @@ def test_pmc_profile_is_reported_only_for_the_build_it_was_taken_on(tmp_path, mo
             for base, e in w["kernels"].items():
                 for k in entry:
                     assert (e[k] > 0) if k != "kernel" else e[k].startswith(base), (base, k)
+
+def test_roofline_entry_names_the_tier_that_serves_the_bytes(monkeypatch):
+    """bench.py's roofline object (CPU-only): the bound follows the MEASURED fabric traffic when PMC passes of this build
+    exist — under 30 % of the HBM peak the kernel is priced against the L2 aggregate as "latency/issue", never as a
+    fraction above 1 of "hbm" — and a lane's launch is charged its share of a whole batch's counters."""
+    sys.path.insert(0, ROOT)
+    import bench
+    entry = {"kernel": "k_extend<false, true, 0>", "ea_dram_read_bytes_per_launch": 8.0e9, "ea_dram_write_bytes_per_launch": 6.0e9,
+             "l2_hit_rate": 0.55, "valu_insts_per_launch": 7.0e9, "inst_active_frac": 0.42, "wait_any_frac": 0.41, "wait_inst_frac": 0.17}
+    monkeypatch.setattr(bench, "_pmc_for", lambda key, kernel: (entry, "fake"))
+    # one whole-batch launch: 160 GB algorithmic in 12.8 ms = 12.5 TB/s > the HBM peak; measured 14 GB = 0.137 of it
+    e = bench._roofline_entry("k_extend", 160.0e9, 12.8 * 24, 24, 2, "w", 1)
+    assert e["bound"] == "latency/issue" and e["peak"] == bench.L2_PEAK_GBS and 0.3 < e["frac"] < 0.4
+    assert abs(e["hbm_measured_frac"] - 14.0e9 / 12.8e-3 / 1e9 / 8000.0) < 1e-3 and e["hbm_frac_algorithmic"] > 1.0
+    # the same kernel as one of four overlapping lanes: a quarter of the counters per launch
+    q = bench._roofline_entry("k_extend", 40.0e9, 11.0 * 96, 96, 2, "w", 1, traffic_scale=0.25)
+    assert q["traffic"] == int(14.0e9 * 0.25) and q["bound"] == "latency/issue"
+    # a streaming kernel whose measured traffic is above 30 % of the HBM peak is priced against HBM, fraction <= 1
+    entry2 = dict(entry, ea_dram_read_bytes_per_launch=12.0e9, ea_dram_write_bytes_per_launch=6.0e9)
+    monkeypatch.setattr(bench, "_pmc_for", lambda key, kernel: (entry2, "fake"))
+    h = bench._roofline_entry("k_shade", 40.0e9, 6.8 * 24, 24, 2, "w", 1)
+    assert h["bound"] == "hbm" and h["peak"] == bench.HBM_PEAK_GBS and h["frac"] <= 1.0
+    # no PMC passes for this build: decided from the algorithmic rate alone
+    monkeypatch.setattr(bench, "_pmc_for", lambda key, kernel: (None, "none"))
+    n = bench._roofline_entry("k_extend", 160.0e9, 12.8 * 24, 24, 2, "w", 1)
+    assert n["traffic"] is None and n["bound"] == "latency/issue" and n["frac"] < 1.0
