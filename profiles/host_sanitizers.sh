@@ -14,4 +14,17 @@ cd $R
 RT=$(find /opt/rocm/lib/llvm -name "libclang_rt.asan-x86_64.so" | head -1)
 CRT_AMD_LIB=$T/libcrt_asan.so LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:abort_on_error=0 UBSAN_OPTIONS=print_stacktrace=1 \
   python -m pytest tests/test_build_parity.py tests/test_abi.py tests/test_stress_scene.py -q -p no:cacheprovider 2>&1 | tee $T/run.log | tail -3
-echo "sanitizer reports: $(grep -c 'runtime error\|ERROR: AddressSanitizer' $T/run.log)"
+echo "ASan / UBSan reports: $(grep -c 'runtime error\|ERROR: AddressSanitizer' $T/run.log)"
+# ... and under ThreadSanitizer: the builder forks subtrees onto helper threads (bvh_build.cpp); the parity and stress
+# scene tests commit trees large enough to fork (43 200 triangles, the 382 804-triangle stress scene, MedCity)
+T2=${TMPDIR:-/tmp}/crt_tsan; mkdir -p $T2; cd $R/crust-render_amd/csrc
+F2="--offload-arch=gfx950 -g -fPIC -std=c++17 -ffp-contract=off -fno-fast-math -I../../include -fsanitize=thread -fno-gpu-sanitize -fno-omit-frame-pointer"
+for f in bvh_build scene capi; do /opt/rocm/bin/hipcc $F2 -O1 -x hip -c $f.cpp -o $T2/$f.o 2>/dev/null & done
+for f in traverse pathtrace; do /opt/rocm/bin/hipcc $F2 -O2 -fno-slp-vectorize -c kernels/$f.hip -o $T2/$f.o 2>/dev/null & done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=thread -fno-gpu-sanitize -o $T2/libcrt_tsan.so $T2/*.o -lpthread
+cd $R
+RT2=$(find /opt/rocm/lib/llvm -name "libclang_rt.tsan-x86_64.so" | head -1)
+CRT_AMD_LIB=$T2/libcrt_tsan.so LD_PRELOAD=$RT2 TSAN_OPTIONS="halt_on_error=0" \
+  python -m pytest tests/test_build_parity.py tests/test_stress_scene.py -q -p no:cacheprovider 2>&1 | tee $T2/run.log | tail -3
+echo "TSan reports: $(grep -c 'WARNING: ThreadSanitizer' $T2/run.log)"
