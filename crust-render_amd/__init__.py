@@ -161,6 +161,9 @@ ABI_SYMBOLS = [
     "crt_film_read", "crt_film_clear", "crt_renderer_active_pixels", "crt_renderer_sample_counts", "crt_render_stats", "crt_renderer_profile", "crt_renderer_profile_read",
     "crt_render_samples_stats", "crt_version", "crt_last_error", "crt_device_info",
     "crt_scene_primitive_extents", "crt_scene_traversal_error", "crt_thread_release", "crt_renderer_shade_class_stats", "crt_renderer_pipeline", "crt_renderer_lanes", "crt_scene_image_check",
+    "crt_scene_engine_select",
+    "crt_material_scatter_n", "crt_material_eval_n", "crt_material_emitted_n", "crt_light_sample_n", "crt_light_pdf_n",
+    "crt_light_escaped_n",
 ]
 
 _lib = None
@@ -212,6 +215,8 @@ def lib():
     L.crt_scene_memory_footprint.argtypes = [vp, C.POINTER(C.c_size_t)]
     if hasattr(L, "crt_scene_image_check"):  # absent from older A/B variant libraries
         L.crt_scene_image_check.argtypes = [vp, C.POINTER(C.c_uint64)]
+    if hasattr(L, "crt_scene_engine_select"):  # absent from older A/B variant libraries
+        L.crt_scene_engine_select.argtypes = [vp, C.c_int, C.POINTER(C.c_uint32)]
     L.crt_scene_tree.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                  C.POINTER(up)]
     L.crt_intersect1.argtypes = [vp, C.POINTER(CrtRay), C.c_float, C.c_float, C.POINTER(CrtRayHit)]
@@ -250,6 +255,10 @@ def lib():
             L.crt_renderer_shade_class_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.crt_renderer_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         L.crt_render_samples_stats.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.POINTER(CrtTravStats)]
+    for name in ("crt_material_scatter_n", "crt_material_eval_n", "crt_material_emitted_n", "crt_light_sample_n",
+                 "crt_light_pdf_n", "crt_light_escaped_n"):  # the shading seam (shading.py)
+        if hasattr(L, name):
+            getattr(L, name).argtypes = [vp, C.c_size_t, vp, C.c_size_t, vp, vp]
     _lib = L
     return L
 
@@ -378,6 +387,15 @@ class Scene:
         _check(lib().crt_scene_image_check(self.h, out), "crt_scene_image_check")
         return dict(zip(("nodes", "leaf_words_plain", "leaf_words_direct_index", "leaf_words_direct_instance", "instances",
                          "moving_instances", "staged_roots", "direct_leaves"), map(int, out)))
+
+    def engine_select(self, want_wide=-1):
+        """Which traversal-engine instance the library selects for this scene's image (crt.h, crt_scene_engine_select;
+        host-only). want_wide: -1 the scene's preference, 0 / 1 asked for (CrtError CRT_ERR_UNSUPPORTED when the image
+        cannot be decoded by it), -2 what a launch in this process would pick (CRT_WIDE included)."""
+        out = (C.c_uint32 * 8)()
+        _check(lib().crt_scene_engine_select(self.h, int(want_wide), out), "crt_scene_engine_select")
+        return dict(zip(("wide", "direct", "lds_stack", "window", "ext_cold", "path_cold", "direct_words", "cold"),
+                        map(int, out)))
 
     def memory_footprint(self):
         out = (C.c_size_t * 6)()
@@ -795,4 +813,5 @@ from . import usdc  # noqa: E402,F401  (the USDC crate reader)
 from . import shard  # noqa: E402,F401  (pixel-tile sharding + the tile gather)
 from . import exr  # noqa: E402,F401  (EXR writer / reader + the reference's exr_diff metrics)
 from . import stats  # noqa: E402,F401  (RenderStats + the reference's report layout)
+from . import shading  # noqa: E402,F401  (Material / Light as batched device functions: the shading seam)
 from . import synthetic  # noqa: E402,F401  (scenes built in code: the labelled stand-in for BASELINE config 5)

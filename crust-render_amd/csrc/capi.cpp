@@ -222,6 +222,15 @@ int crt_scene_image_check(CrtScene *s, uint64_t out[8]) {
     return CRT_ERR_BAD_ARG;
   }
 }
+int crt_scene_engine_select(CrtScene *s, int want_wide, uint32_t out[8]) {
+  if (!s || !out) return CRT_ERR_BAD_ARG;
+  try {
+    return scene_engine_select(*s->p, want_wide, out);
+  } catch (const std::exception &e) {
+    set_error_text("crt_scene_engine_select: %s", e.what());
+    return CRT_ERR_BAD_ARG;
+  }
+}
 int crt_scene_memory_footprint(CrtScene *s, size_t out[6]) {
   if (!s || !out) return CRT_ERR_BAD_ARG;
   int rc = s->p->ensure_device();

@@ -196,7 +196,64 @@ constexpr uint32_t kDirectIndexMask = 0x07ffffffu;
 // stack. Measured (profiles/README.md): the renderer's per-stage pipeline on them gains 4-9 % on cornellbox, veach_mis,
 // sun_sky (at most a few hundred nodes); 16 M incoherent rays against 43 200 triangles (3 600 nodes, 15 nodes per ray)
 // lose 7 %, an instanced city 6 %, sphere-only scenes are indifferent.
-inline bool wide_split(const DevScene &s) { return s.pool_stack < 10u && s.n_packets > 0 && s.n_nodes <= 1024u; }
+// ... and only images WITHOUT direct child words: the four-wave kernels are built without the direct-leaf engine copy
+// (run_traversal), so a direct word would be read as a leaf index (the round-3 fault, profiles/README.md).
+inline bool wide_split(const DevScene &s) {
+  return s.direct_leaves == 0 && s.pool_stack < 10u && s.n_packets > 0 && s.n_nodes <= 1024u;
+}
+
+// LDS stack entries per ray of the three engine splits (kernels/traverse_pool.hip.h sizes its arenas from these).
+#ifndef CRT_POOL_STACK
+#define CRT_POOL_STACK 6        // flat scenes, three-wave kernels
+#endif
+#ifndef CRT_POOL_STACK_DEEP
+#define CRT_POOL_STACK_DEEP 10  // instance-heavy scenes and large trees, three-wave kernels
+#endif
+#ifndef CRT_POOL_STACK_WIDE
+#define CRT_POOL_STACK_WIDE 3   // four-wave kernels
+#endif
+
+// Which instance of the traversal engine runs an image. THE one decision: the renderer (pathtrace.hip), the batched and
+// the single-ray queries (traverse.hip) and the host-only crt_scene_engine_select all call select_engine, and every
+// launch goes through the EngineSelect it returns — an engine instance never meets an image form it was not built for
+// (rounds 2 and 3 each lost a GPU box to exactly that: profiles/README.md, "The r02f abort", "The r03w fault").
+struct EngineSelect {
+  bool wide = false;       // the four-workgroups-per-CU kernels (WIDE): no direct form, three LDS stack entries
+  bool direct = false;     // the DIRECT engine copy of the three-wave kernels: reads direct child words, root test at entry
+  uint32_t lds_stack = CRT_POOL_STACK;  // stack entries per ray in LDS
+  uint32_t window = CRT_POOL_NODES;     // nodes staged in LDS per workgroup
+  int ext_cold = (int)kColdAll;         // k_extend<., ., COLD>: none / the pending normal only / everything
+  int path_cold = (int)kColdAll;        // k_path<., ., COLD> of simple scenes: none / everything
+};
+// want_wide: -1 = the scene's own preference (wide_split), 0 / 1 = asked for (CRT_WIDE, tests). CRT_OK, or
+// CRT_ERR_UNSUPPORTED when what was asked for cannot decode the image — nothing is launched then.
+inline int select_engine(const DevScene &s, int want_wide, EngineSelect &e) {
+  const bool has_direct_words = s.direct_leaves != 0;
+  if (want_wide > 0 && has_direct_words) return CRT_ERR_UNSUPPORTED;  // WIDE kernels carry no direct-leaf engine
+  e.wide = want_wide < 0 ? wide_split(s) : want_wide != 0;
+  e.direct = !e.wide && CRT_DIRECT_LEAVES != 0 && has_direct_words;
+  if (has_direct_words && !e.direct) return CRT_ERR_UNSUPPORTED;      // (a build without the direct form never writes one)
+  const bool deep = s.pool_stack >= (uint32_t)CRT_POOL_STACK_DEEP;    // run_traversal's rule
+  e.lds_stack = e.wide ? (uint32_t)CRT_POOL_STACK_WIDE : (deep ? (uint32_t)CRT_POOL_STACK_DEEP : (uint32_t)CRT_POOL_STACK);
+  e.window = e.wide ? (uint32_t)CRT_POOL_NODES_WIDE : (deep ? (uint32_t)CRT_POOL_NODES_DEEP : (uint32_t)CRT_POOL_NODES);
+  const int cold = (int)(s.cold & kColdAll);
+  e.ext_cold = cold == 0 ? 0 : (cold == (int)kColdNormal ? (int)kColdNormal : (int)kColdAll);
+  e.path_cold = cold == 0 ? 0 : (int)kColdAll;
+  return CRT_OK;
+}
+// The check every launch site makes on the EngineSelect it was handed (defence in depth: select_engine already
+// guarantees it): the instance can decode every child word of the image and keeps every cold field the image can need.
+inline bool engine_accepts(const EngineSelect &e, const DevScene &s, int kernel_cold) {
+  if (s.direct_leaves != 0 && (e.wide || !e.direct)) return false;
+  return ((int)(s.cold & kColdAll) & ~kernel_cold) == 0;
+}
+// CRT_WIDE (A/B runs, tests): 1 asks for the four-wave kernels, 0 for the three-wave ones. A request the image cannot
+// take falls back to the scene's own preference — the knob sweeps whole test sets, direct-leaf scenes included.
+int wide_request();  // -1 unset
+inline int select_engine_env(const DevScene &s, EngineSelect &e) {
+  if (select_engine(s, wide_request(), e) == CRT_OK) return CRT_OK;
+  return select_engine(s, -1, e);
+}
 
 struct DeviceImage {
   void *blob = nullptr;
@@ -219,6 +276,8 @@ struct Scene : std::enable_shared_from_this<Scene> {
 // Host-only self-check of the image Scene::ensure_device would upload (scene.cpp): CRT_OK and eight counts, or
 // CRT_ERR_BAD_ARG with the broken invariant in crt_last_error.
 int scene_image_check(const Scene &scene, uint64_t out[8]);
+// Host-only: select_engine on the image this scene would upload, verified against a census of the image (scene.cpp).
+int scene_engine_select(const Scene &scene, int want_wide, uint32_t out[8]);
 
 enum GeomKind { G_MESH, G_SPHERE, G_INSTANCE };
 struct Geom {

@@ -1165,9 +1165,11 @@ struct Renderer {
   // with the WIDE traversal kernels (four workgroups per CU). The scene decides which one it prefers (crt_renderer_new:
   // `wide`), the batch whether the per-stage form pays: its 2-3 launches per bounce cost ~0.8 ms per batch, worth it from
   // `stage_min_paths` paths up. CRT_FUSED / CRT_WIDE / CRT_STAGE_MIN_PATHS override (A/B, per-stage timing, tests).
-  bool wide = false;       // the scene's preference (wide_split)
+  EngineSelect engine;     // which traversal-engine instance runs this scene's image (crt_internal.h, select_engine)
+  bool wide = false;       // = engine.wide: the scene prefers the per-stage pipeline on the four-wave kernels
   bool cam_compact_ok = true;  // CRT_CAM_COMPACT
   int shade_wide = -1;            // CRT_SHADE_WIDE: 0 = the three-wave shade kernels even beside four-wave traversal kernels (A/B)
+  size_t max_batch_slots = 0;     // CRT_MAX_BATCH_SLOTS (tests): ensure_buffers fails above this many slots; 0 = no limit
   int tail_from = 12;             // CRT_TAIL_FROM: the bounce from which a per-stage batch finishes in one fused launch
   int noclassify_from = 1 << 30;  // CRT_NOCLASSIFY_FROM: per-stage shade without its CLASSIFY pass from this bounce on
   int force_fused = -1;    // CRT_FUSED: -1 unset
@@ -1254,7 +1256,16 @@ struct Renderer {
     const bool lit = P.n_lights > 0, motion = P.has_motion != 0;
     // 2 x (a b c d [e] [16 B] + [time 4 B]) + hit (16 + 4) + shadow 3 x 16 + staging 16
     blob_bytes = 2 * ((lit ? 5 : 4) * b16 + (motion ? b4 : 0)) + (b16 + b4) + (lit ? 3 * p16 : 0) + p16;
-    if (!CRT_HIP_OK(hipMalloc(&blob, blob_bytes))) return CRT_ERR_NO_DEVICE;
+    // CRT_MAX_BATCH_SLOTS (tests): a batch of more slots asks for more memory than any device has, so the allocation
+    // fails the way it does on a part with too little free HBM (bench.py halves the batch then).
+    const size_t want_bytes = (max_batch_slots && slots > max_batch_slots) ? ((size_t)1 << 46) : blob_bytes;
+    if (!CRT_HIP_OK(hipMalloc(&blob, want_bytes))) {
+      // hipGetLastError returns the last ERROR, not the last call's status: left in place, the out-of-memory would be
+      // reported by the next successful batch's launch check (a retry with a smaller batch would fail for no reason)
+      (void)hipGetLastError();
+      blob = nullptr; blob_bytes = 0; cap_slots = 0;
+      return CRT_ERR_NO_DEVICE;
+    }
     char *cur_p = blob;
     auto take = [&](size_t bytes) { char *r = cur_p; cur_p += bytes; return r; };
     for (int b = 0; b < 2; b++) {
@@ -1284,6 +1295,7 @@ struct Renderer {
   int render(uint32_t sample_begin, uint32_t n_samples, hipStream_t st, CrtTravStats *d_tstats) {
     if (n_samples == 0) return CRT_OK;
     if (n_samples > 0xffffu) return CRT_ERR_BAD_ARG;
+    (void)hipGetLastError();  // launches below are checked against a clean slate, not against an earlier call's error
     last_stream = st;
     // how many lanes: one for the stats build and adaptive stopping (the active list changes between batches) and for
     // batches too small to fill the chip twice over
@@ -1308,28 +1320,54 @@ struct Renderer {
       if (!B.stream && !CRT_HIP_OK(hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking))) return CRT_ERR_NO_DEVICE;
       if (!B.done && !CRT_HIP_OK(hipEventCreateWithFlags(&B.done, hipEventDisableTiming))) return CRT_ERR_NO_DEVICE;
     }
-    // every lane starts behind what the caller's stream has queued (the previous batch's film fold reads the staging
-    // films this batch overwrites); lane 0 IS the caller's stream
-    if (!CRT_HIP_OK(hipEventRecord(ev_start, st))) return CRT_ERR_NO_DEVICE;
     uint32_t begin[kMaxLanes], count[kMaxLanes];
     for (int l = 0; l < L; l++) {
       count[l] = n_samples / L + ((uint32_t)l < n_samples % L ? 1u : 0u);
       begin[l] = l == 0 ? sample_begin : begin[l - 1] + count[l - 1];
     }
+    // every lane's buffers BEFORE any launch: an allocation that fails then fails with nothing of this batch in flight
+    for (int l = 0; l < L; l++) {
+      Params scratch = P;
+      const int rc = plan_lane(lanes[l], scratch, count[l], nullptr);
+      if (rc != CRT_OK) return rc;
+    }
+    // every lane starts behind what the caller's stream has queued (the previous batch's film fold reads the staging
+    // films this batch overwrites); lane 0 IS the caller's stream
+    if (!CRT_HIP_OK(hipEventRecord(ev_start, st))) return CRT_ERR_NO_DEVICE;
+    // a failure from here on leaves launches in flight on the lanes' own (non-blocking) streams, which nothing the caller
+    // does afterwards waits for (crt_render_stats, crt_film_clear, a retry sync only the caller's stream): drain them
+    auto fail = [&](int rc) {
+      for (int l = 1; l < L; l++)
+        if (lanes[l].stream) (void)hipStreamSynchronize(lanes[l].stream);
+      (void)hipStreamSynchronize(st);
+      return rc;
+    };
     // the lanes on their own streams first, lane 0 on the caller's last: its launches then queue behind nothing of ours
     for (int l = L - 1; l >= 0; l--) {
       hipStream_t ls = l == 0 ? st : lanes[l].stream;
-      if (l > 0 && !CRT_HIP_OK(hipStreamWaitEvent(ls, ev_start, 0))) return CRT_ERR_NO_DEVICE;
+      if (l > 0 && !CRT_HIP_OK(hipStreamWaitEvent(ls, ev_start, 0))) return fail(CRT_ERR_NO_DEVICE);
       const int rc = render_lane(lanes[l], begin[l], count[l], ls, nullptr, false);
-      if (rc != CRT_OK) return rc;
-      if (l > 0 && !CRT_HIP_OK(hipEventRecord(lanes[l].done, ls))) return CRT_ERR_NO_DEVICE;
+      if (rc != CRT_OK) return fail(rc);
+      if (l > 0 && !CRT_HIP_OK(hipEventRecord(lanes[l].done, ls))) return fail(CRT_ERR_NO_DEVICE);
     }
     // the film fold: lane after lane on the caller's stream = sample order
     for (int l = 0; l < L; l++) {
-      if (l > 0 && !CRT_HIP_OK(hipStreamWaitEvent(st, lanes[l].done, 0))) return CRT_ERR_NO_DEVICE;
+      if (l > 0 && !CRT_HIP_OK(hipStreamWaitEvent(st, lanes[l].done, 0))) return fail(CRT_ERR_NO_DEVICE);
       timed(3, st, [&] { hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(kBlock), 0, st, lanes[l].staging, P.n_pix, count[l], film); });
     }
-    return CRT_HIP_OK(hipGetLastError()) ? CRT_OK : CRT_ERR_NO_DEVICE;
+    return CRT_HIP_OK(hipGetLastError()) ? CRT_OK : fail(CRT_ERR_NO_DEVICE);
+  }
+
+  // Pipeline, grid and segment size of one lane's batch of n_samples, and its buffers (they grow when a batch needs
+  // more slots than any before). Sets fused / grid for the launches that follow and p.seg_cap.
+  int plan_lane(Lane &B, Params &p, uint32_t n_samples, CrtTravStats *d_tstats) {
+    const size_t total = (size_t)p.n_act * n_samples;
+    fused = force_fused >= 0 ? force_fused != 0 : !(wide && total >= stage_min_paths);
+    if (d_tstats) fused = false;  // the stats build is the per-stage one
+    if (P.has_inf_lights) fused = false;  // no fused instance for lights at infinity (see k_path)
+    grid = batch_grid(total, fused);
+    p.seg_cap = (uint32_t)(((total + (size_t)grid * kBlock - 1) / ((size_t)grid * kBlock)) * kBlock);
+    return ensure_buffers(B, (size_t)p.seg_cap * grid);  // >= total: the staging film's (sample, active pixel) slots too
   }
 
   int render_lane(Lane &B, uint32_t sample_begin, uint32_t n_samples, hipStream_t st, CrtTravStats *d_tstats, bool fold_here) {
@@ -1343,16 +1381,7 @@ struct Renderer {
     p.sample_begin = sample_begin;
     p.n_act = adaptive ? n_act : P.n_pix;
     p.active = (adaptive && n_act < P.n_pix) ? d_active : nullptr;
-    {  // pipeline, grid and segment size for THIS batch; the buffers grow when a batch needs more slots than any before
-      const size_t total = (size_t)p.n_act * n_samples;
-      fused = force_fused >= 0 ? force_fused != 0 : !(wide && total >= stage_min_paths);
-      if (d_tstats) fused = false;  // the stats build is the per-stage one
-      if (P.has_inf_lights) fused = false;  // no fused instance for lights at infinity (see k_path)
-      grid = batch_grid(total, fused);
-      p.seg_cap = (uint32_t)(((total + (size_t)grid * kBlock - 1) / ((size_t)grid * kBlock)) * kBlock);
-      const int rc = ensure_buffers(B, (size_t)p.seg_cap * grid);  // >= total: the staging film's (sample, active pixel) slots too
-      if (rc != CRT_OK) return rc;
-    }
+    if (const int rc = plan_lane(B, p, n_samples, d_tstats)) return rc;
     float4 *staging = B.staging;
     const bool wide = !fused && this->wide;  // per-stage launches take the scene's preferred traversal kernels
     // camera paths as 16-byte records: per-stage launches of an UNLIT scene, pinhole camera, static scene
@@ -1379,10 +1408,21 @@ struct Renderer {
     };
     const bool lit = P.n_lights > 0;  // the kernel instance; whether the strategy samples the lights is checked in shade
     // the cold per-ray state the scene can need (DevScene::cold) picks the closest-hit kernels' instance: none / the
-    // pending normal only / everything for the per-stage k_extend, none / everything for the fused kernel of simple scenes
-    const int scene_cold = (int)P.scene.cold;
-    const int ext_cold = scene_cold == 0 ? 0 : (scene_cold == (int)kColdNormal ? (int)kColdNormal : (int)kColdAll);
-    const int path_cold = scene_cold == 0 ? 0 : (int)kColdAll;
+    // pending normal only / everything for the per-stage k_extend, none / everything for the fused kernel of simple
+    // scenes — decided by select_engine, with the image in hand; a launch the image cannot take is refused, never made
+    const int ext_cold = d_tstats ? (int)kColdAll : engine.ext_cold;
+    const int path_cold = mats_kind == 0 ? engine.path_cold : (int)kColdAll;
+    {
+      EngineSelect launched = engine;
+      launched.wide = wide;  // the fused kernel is a three-wave kernel whatever the scene prefers
+      launched.direct = !wide && CRT_DIRECT_LEAVES != 0 && P.scene.direct_leaves != 0;  // run_traversal picks the copy from the image
+      const bool tail = !fused && tail_from > 0 && !d_tstats && !P.has_inf_lights;
+      if (!engine_accepts(launched, P.scene, fused ? path_cold : (tail ? (ext_cold & path_cold) : ext_cold))) {
+        set_error_text("render refused: the selected kernels (wide %d, cold %d / %d) cannot run this image (direct words %u, cold %u)",
+                       (int)wide, ext_cold, path_cold, P.scene.direct_leaves, P.scene.cold);
+        return CRT_ERR_UNSUPPORTED;
+      }
+    }
     if (fused) {  // one launch for the whole path loop (class 0 of the profile), then the film fold
       timed(0, st, [&] {
 #define CRT_PATH(M, L, CO) \
@@ -1617,13 +1657,18 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
   // the fourth wave per SIMD of the per-stage kernels; an instanced city loses 6 % to their four-entry LDS stack, and a
   // scene of analytic spheres only (openpbr_showcase: next to no traversal, all shading) 1 % to the hit records' round
   // trip (profiles/README.md).
-  r.wide = wide_split(P.scene);
-  // CRT_WIDE=1 forces the four-wave kernels (A/B, tests) — except on a direct-leaf scene: those kernels are built
-  // without the direct form (run_traversal) and must never meet a direct child word
-  if (const char *e = getenv("CRT_WIDE")) r.wide = atoi(e) != 0 && P.scene.direct_leaves == 0;
+  // select_engine decides, from the image, which engine instance runs it; CRT_WIDE=0/1 (A/B, tests) is a request it
+  // honours only where the image can be decoded by what was asked for (never the four-wave kernels on direct words)
+  if (select_engine_env(P.scene, r.engine) != CRT_OK) {
+    set_error_text("crt_renderer_new: no traversal-engine instance of this build can decode the scene image");
+    delete R;
+    return nullptr;
+  }
+  r.wide = r.engine.wide;
   if (const char *e = getenv("CRT_CAM_COMPACT")) r.cam_compact_ok = atoi(e) != 0;
   if (const char *e = getenv("CRT_NOCLASSIFY_FROM")) r.noclassify_from = atoi(e);
   if (const char *e = getenv("CRT_TAIL_FROM")) r.tail_from = atoi(e);
+  if (const char *e = getenv("CRT_MAX_BATCH_SLOTS")) r.max_batch_slots = (size_t)strtoull(e, nullptr, 10);
   if (const char *e = getenv("CRT_LANES")) { const int n = atoi(e); r.n_lanes = n < 1 ? 1 : (n > Renderer::kMaxLanes ? Renderer::kMaxLanes : n); }
   if (const char *e = getenv("CRT_LANE_MIN_PATHS")) r.lane_min_paths = (size_t)strtoull(e, nullptr, 10);
   if (const char *e = getenv("CRT_SHADE_WIDE")) r.shade_wide = atoi(e) != 0 ? 1 : 0;

@@ -116,10 +116,17 @@ __global__ __launch_bounds__(kBlock, WIDE ? 4 : 3) void occluded_n_kernel(DevSce
 }
 
 // Small flat triangle scenes run the WIDE kernels (four workgroups resident per CU), the others the scene's own split
-// on three (crt_internal.h, wide_split).
-bool wide_scene(const DevScene &s) {
-  if (const char *e = getenv("CRT_WIDE")) return atoi(e) != 0 && s.direct_leaves == 0;  // A/B runs, tests; never a direct-leaf scene (run_traversal)
-  return wide_split(s);
+// on three: crt_internal.h, select_engine — the one place that decides, from the image, which engine instance runs it.
+// The batched queries report u and v and keep every cold field (kColdAll).
+int query_engine(const DevScene &s, EngineSelect &e) {
+  const int rc = select_engine_env(s, e);
+  if (rc != CRT_OK) return rc;
+  if (!engine_accepts(e, s, (int)kColdAll)) {
+    set_error_text("traversal launch refused: the selected engine instance (wide %d, direct %d) cannot decode this image (direct words %u)",
+                   (int)e.wide, (int)e.direct, s.direct_leaves);
+    return CRT_ERR_UNSUPPORTED;
+  }
+  return CRT_OK;
 }
 int grid_for(size_t n, bool wide) {
   static int cus = [] {
@@ -136,11 +143,18 @@ int grid_for(size_t n, bool wide) {
 
 }  // namespace
 
+int wide_request() {
+  const char *e = getenv("CRT_WIDE");
+  return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+}
+
 int launch_intersect_n(const DevScene &s, const CrtRay *d_rays, size_t n, float t_min, float t_max, CrtRayHit *d_hits,
                        void *stream, CrtTravStats *d_stats, uint32_t *e) {
   if (n == 0) return CRT_OK;
   if (!e) return CRT_ERR_BAD_ARG;
-  const bool wide = wide_scene(s);
+  EngineSelect eng;
+  if (const int rc = query_engine(s, eng)) return rc;
+  const bool wide = eng.wide;
   const int grid = grid_for(n, wide);
 #define CRT_LAUNCH(ST, W)                                                                                             \
   hipLaunchKernelGGL((intersect_n_kernel<ST, W>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, s, d_rays, n, t_min, \
@@ -155,7 +169,9 @@ int launch_occluded_n(const DevScene &s, const CrtRay *d_rays, size_t n, float t
                       void *stream, CrtTravStats *d_stats, uint32_t *e) {
   if (n == 0) return CRT_OK;
   if (!e) return CRT_ERR_BAD_ARG;
-  const bool wide = wide_scene(s);
+  EngineSelect eng;
+  if (const int rc = query_engine(s, eng)) return rc;
+  const bool wide = eng.wide;
   const int grid = grid_for(n, wide);
 #define CRT_LAUNCH(ST, W)                                                                                            \
   hipLaunchKernelGGL((occluded_n_kernel<ST, W>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, s, d_rays, n, t_min, \

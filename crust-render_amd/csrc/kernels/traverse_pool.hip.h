@@ -21,9 +21,6 @@
 namespace crt {
 namespace dev {
 
-#ifndef CRT_POOL_STACK
-#define CRT_POOL_STACK 6
-#endif
 #ifndef CRT_ROOT_REJECT
 #define CRT_ROOT_REJECT 1  // an instanced tree's root node is tested at entry; rays that touch no child never enter
 #endif
@@ -47,10 +44,7 @@ namespace dev {
 // deeper than six entries and profits from the node window; instance-heavy scenes stack the parent's entries under
 // the instance's and run +6 % with ten entries and next to no window (profiles/README.md). The host picks the split
 // per scene (DevScene::pool_stack); both fit the same arena.
-constexpr int kPoolStack = CRT_POOL_STACK;       // flat scenes
-#ifndef CRT_POOL_STACK_DEEP
-#define CRT_POOL_STACK_DEEP 10
-#endif
+constexpr int kPoolStack = CRT_POOL_STACK;       // flat scenes (the three CRT_POOL_STACK* defaults: crt_internal.h)
 constexpr int kPoolStackDeep = CRT_POOL_STACK_DEEP;  // instance-heavy scenes
 // Private part of the stack. sp lives in 8 bits of the ctl word, so LDS part + private part must not exceed 255 with
 // EITHER split: a push at the limit then takes the err path (CRT_ERR_STACK) instead of wrapping into `base`.
@@ -937,9 +931,6 @@ constexpr int kEngineLdsDwords = kEngineLdsFlat > kEngineLdsDeep ? kEngineLdsFla
 // the per-stage pipeline on it over the fused kernel on three; an instanced city, whose rays stack the parent's entries
 // under the instance's, loses 6 %: profiles/README.md). The renderer and the batched queries pick it per scene
 // (crt_internal.h, wide_split).
-#ifndef CRT_POOL_STACK_WIDE
-#define CRT_POOL_STACK_WIDE 3
-#endif
 constexpr int kPoolStackWide = CRT_POOL_STACK_WIDE;
 constexpr int kPoolNodesWide = CRT_POOL_NODES_WIDE;  // crt_internal.h
 constexpr int kEngineLdsWide = (kBlock / 64) * pool_lds_dwords<CRT_POOL_ROWS>(kPoolStackWide) + kPoolNodesWide * kLdsNodeStride;

@@ -360,7 +360,8 @@ int flatten_image(const Scene &scene, FlatImage &im) {
   const bool many_instances = f.instances.size() >= 64;
   const bool large_tree = f.nodes.size() > 2048;
   uint32_t pool_stack = (many_instances || large_tree) ? 10u : 6u;
-  if (const char *e = getenv("CRT_POOL_STACK_RT")) pool_stack = (uint32_t)atoi(e);  // A/B runs
+  // A/B runs: the split, not a number — anything from the deep split's entry count up is the deep one, all else the flat
+  if (const char *e = getenv("CRT_POOL_STACK_RT")) pool_stack = atoi(e) >= CRT_POOL_STACK_DEEP ? (uint32_t)CRT_POOL_STACK_DEEP : (uint32_t)CRT_POOL_STACK;
   im.pool_stack = pool_stack;
   const bool deep = pool_stack >= 10u;  // run_traversal's rule for the window size
   // Renumber the nodes for the window the kernels stage in LDS (the first nodes of the array; 72 / 16 / 26 of them
@@ -576,6 +577,62 @@ int scene_image_check(const Scene &scene, uint64_t out[8]) {
   return CRT_OK;
 }
 
+namespace {
+// The scene view's fields that do not depend on where the image lives (everything but the seven pointers).
+void fill_view_fields(const FlatImage &im, DevScene &v) {
+  v.root = im.me.root;
+  v.has_packets = im.me.has_packets;
+  v.n_nodes = uint32_t(im.f.nodes.size());
+  v.n_packets = uint32_t(im.f.packets.size());
+  v.direct_leaves = im.direct ? 1u : 0u;
+  v.pool_stack = im.pool_stack;
+  v.cold = im.cold;
+}
+}  // namespace
+
+// Host-only: which traversal-engine instance select_engine picks for the image this scene would upload (want_wide: -1
+// the scene's preference, 0 / 1 asked for), checked against a census of the image's child words and primitives — the
+// instance must be able to decode every word and must keep every cold field a primitive of the image can need.
+// out: wide | direct engine copy | LDS stack entries | node window | k_extend cold | k_path cold | direct words | DevScene::cold
+int scene_engine_select(const Scene &scene, int want_wide, uint32_t out[8]) {
+  FlatImage im;
+  int rc = flatten_image(scene, im);
+  if (rc != CRT_OK) return rc;
+  DevScene v{};
+  fill_view_fields(im, v);
+  EngineSelect e;
+  rc = want_wide == -2 ? select_engine_env(v, e) : select_engine(v, want_wide, e);  // -2: as the launches decide, CRT_WIDE included
+  if (rc != CRT_OK) {
+    set_error_text("select_engine: the %s kernels cannot decode this image (direct child words: %s)",
+                   want_wide > 0 ? "four-wave" : "three-wave", v.direct_leaves ? "yes" : "no");
+    return rc;
+  }
+  uint32_t n_direct = 0, need_cold = 0;
+  for (const WideNode &n : im.f.nodes)
+    for (int l = 0; l < 4; l++) {
+      const uint32_t w = n.child[l];
+      if (w != CRT_INVALID_ID && (w & 0x80000000u) && (w & kDirectLeafTag)) n_direct++;
+    }
+  for (const DevPrim &d : im.f.prims) {
+    if (d.kind == PRIM_SPHERE) need_cold |= kColdNormal;
+    if (d.kind == PRIM_TRI && f2u(d.d[9]) != 0xFFFFFFFFu) need_cold |= kColdUV;
+  }
+  if (instance_levels(scene) > 1) need_cold |= kColdNormal;
+  if (!im.f.moving.empty()) need_cold |= kColdTime;
+  auto fail = [&](const char *what) {
+    set_error_text("engine select check: %s (wide %d, direct %d, direct words %u, cold %u / kernel %d %d)", what, (int)e.wide,
+                   (int)e.direct, n_direct, need_cold, e.ext_cold, e.path_cold);
+    return CRT_ERR_BAD_ARG;
+  };
+  if (n_direct && (e.wide || !e.direct)) return fail("the image holds direct child words the selected instance cannot read");
+  if (n_direct && !v.direct_leaves) return fail("direct words in an image whose view says there are none");
+  if ((need_cold & ~(uint32_t)e.ext_cold) || (need_cold & ~(uint32_t)e.path_cold)) return fail("the image needs cold state the selected kernels do not keep");
+  if (!engine_accepts(e, v, e.ext_cold) || !engine_accepts(e, v, e.path_cold)) return fail("engine_accepts disagrees with select_engine");
+  out[0] = e.wide; out[1] = e.direct; out[2] = e.lds_stack; out[3] = e.window;
+  out[4] = (uint32_t)e.ext_cold; out[5] = (uint32_t)e.path_cold; out[6] = n_direct; out[7] = v.cold;
+  return CRT_OK;
+}
+
 int Scene::ensure_device() {
   std::lock_guard<std::mutex> lock(dev_mu);
   if (dev) return CRT_OK;
@@ -584,7 +641,6 @@ int Scene::ensure_device() {
   const int rc = flatten_image(*this, im);
   if (rc != CRT_OK) return rc;
   Flat &f = im.f;
-  const Flat::Placed me = im.me;
   auto img = std::make_unique<DeviceImage>();
   constexpr int NA = 7;
   const size_t sz[NA] = {f.nodes.size() * sizeof(WideNode), f.leaves.size() * sizeof(Leaf),
@@ -615,13 +671,7 @@ int Scene::ensure_device() {
   img->view.prims = reinterpret_cast<const DevPrim *>(base + off[4]);
   img->view.instances = reinterpret_cast<const DevInstance *>(base + off[5]);
   img->view.normals = reinterpret_cast<const float *>(base + off[6]);
-  img->view.root = me.root;
-  img->view.has_packets = me.has_packets;
-  img->view.n_nodes = uint32_t(f.nodes.size());
-  img->view.n_packets = uint32_t(f.packets.size());
-  img->view.direct_leaves = im.direct ? 1u : 0u;
-  img->view.pool_stack = im.pool_stack;
-  img->view.cold = im.cold;
+  fill_view_fields(im, img->view);
   dev = std::move(img);
   return CRT_OK;
 }

@@ -134,6 +134,16 @@ int crt_scene_primitive_extents(const CrtScene *s, size_t *count, float *scene_d
  * instanced roots staged for the LDS window | 1 if direct leaves are on. CRT_ERR_BAD_ARG + crt_last_error on a broken
  * invariant. (No reference counterpart: the image is this library's own layout of scene.rs:226-340's commit.) */
 int crt_scene_image_check(CrtScene *s, uint64_t out[8]);
+/* Host-only (no GPU needed): which instance of the traversal engine this library selects for the image the scene would
+ * upload — ONE function decides it for the renderer, the batched and the single-ray queries — verified against a census
+ * of the image: the instance decodes every child word (the four-wave kernels carry no direct-leaf form) and keeps every
+ * rarely used per-ray field some primitive can need. want_wide: -1 = the scene's own preference, 0 / 1 = asked for, -2 =
+ * exactly what a launch would pick in this process (the CRT_WIDE A/B request included, which falls back where refused);
+ * CRT_ERR_UNSUPPORTED when what was asked for cannot decode the image (nothing would be launched), CRT_ERR_BAD_ARG +
+ * crt_last_error on a broken invariant. out: four-wave kernels | direct-leaf engine copy | LDS stack entries per ray |
+ * nodes staged in LDS | cold mask of the per-stage closest-hit kernel | of the fused kernel | direct words in the image |
+ * cold mask the image needs. (No reference counterpart: the reference has one scalar traversal, bvh.rs:441-509.) */
+int crt_scene_engine_select(CrtScene *s, int want_wide, uint32_t out[8]);
 /* memory_footprint: prim_nodes, boxed_prims, bvh_nodes, leaves, packets, indices (device bytes) scene.rs:459 */
 int crt_scene_memory_footprint(CrtScene *s, size_t out[6]);
 /* Host copies of the committed tree of THIS scene (local indices), for build-parity checks:
@@ -212,6 +222,71 @@ typedef struct CrtCamera {
 /* Camera::new(lookfrom, lookat, vup, vfov_deg, aspect, aperture, focus_dist)   camera.rs:27-63 */
 void crt_camera_new(CrtCamera *c, const float lookfrom[3], const float lookat[3], const float vup[3], float vfov_deg,
                     float aspect, float aperture, float focus_dist);
+
+/* ---- the shading seam as callable functions: `trait Material` (material.rs:26-116) and `trait Light` (light.rs:120-151)
+ * for a host integrator that keeps its own trace_path (tracer.rs:1086-1558) on top of crt_intersect_n / crt_occluded_n.
+ * Batched like those: every pointer is a DEVICE pointer, n records, launched on `stream` without synchronising; the
+ * arithmetic is the device code crt_render_samples runs (kernels/shade.hip.h), one query per lane. The material / light
+ * tables are plain arrays of the records above, uploaded by the caller (crt_renderer_new keeps its own copies).
+ * INTEGRATION.md binds them as `impl Material for DeviceMaterial` / `impl Light for DeviceLight`. ---- */
+
+/* One call of a Material method: r_in, rec (HitRecord, hittable.rs:10-36; face_id / face_uv are Ptex-only: out of scope),
+ * and the method's own argument. 80 bytes. */
+typedef struct CrtShadeQuery {
+  float ray_dir[3]; uint32_t material;      /* r_in.direction (unnormalised allowed) | record of the material table   */
+  float p[3]; float t;                      /* rec.p, rec.t                                                            */
+  float normal[3]; uint32_t front_face;     /* rec.normal (faces the ray, scene.rs:356-359), rec.front_face            */
+  float wi[3]; float cos_theta_o;           /* eval: the direction to evaluate | emitted_directional: cos(theta_o)     */
+  uint32_t sampler_pattern, sampler_index;  /* scatter_importance: the PathSampler domain handed over by value          */
+  uint32_t _pad[2];                         /*   (pattern of the domain, sample index: tracer.rs:1121, openpbr.rs:1042) */
+} CrtShadeQuery;
+/* Option<ScatterSample> (material.rs:8-22): some = 0 is None (no field below is meaningful then). 48 bytes. */
+typedef struct CrtScatterSample {
+  float origin[3]; uint32_t some;           /* ray.origin (p, or p + l * 1e-4 across the interface, openpbr.rs:1063)   */
+  float dir[3]; float pdf;                  /* ray.direction (unnormalised as the reference leaves it) | pdf >= 1e-4   */
+  float value[3]; uint32_t flags;           /* brdf * |cos| | bit 0: delta, bit 1: the ray carries the material's      */
+} CrtScatterSample;                         /*   interior medium (Ray::new_in_medium, openpbr.rs:1061-1066)            */
+/* Option<(Vec3A, f32)> of Material::eval (material.rs:56-74). 32 bytes. */
+typedef struct CrtBsdfEval { float value[3]; float pdf; uint32_t some; uint32_t _pad[3]; } CrtBsdfEval;
+/* One call of a Light method. 48 bytes. */
+typedef struct CrtLightQuery {
+  float from[3]; uint32_t light;            /* the shading point | entry of the light list                              */
+  float u, v; uint32_t _pad[2];             /* sample_li: the two unit random numbers                                   */
+  float point[3]; uint32_t _pad2;           /* pdf_at_point: light_point | escaped: the (unit) direction                */
+} CrtLightQuery;
+/* Option<LightSample> (light.rs:90-105); escaped's Option<(radiance, pdf)> uses radiance, pdf and some. 48 bytes. */
+typedef struct CrtLightSample {
+  float direction[3]; float distance;       /* unit, towards the light | INFINITY for lights at infinity                */
+  float radiance[3]; float pdf;
+  uint32_t some; uint32_t _pad[3];
+} CrtLightSample;
+
+/* Material::scatter_importance(r_in, rec, sampler) -> Option<ScatterSample>     material.rs:40-45; OpenPBR
+ * scatter_resolved openpbr.rs:1026-1136 (draws ONE 4-D block from the domain: s[0] lobe, s[1..3] direction, s[3]
+ * dispersion channel); Emissive never scatters (emissive.rs:30-38). A query whose material index is out of range
+ * answers None (the reference would panic on the index). */
+int crt_material_scatter_n(const CrtMaterial *d_materials, size_t n_materials, const CrtShadeQuery *d_queries, size_t n,
+                           CrtScatterSample *d_out, void *stream);
+/* Material::eval(r_in, rec, wi) -> Option<(value = brdf * |cos|, pdf >= 1e-4)>   material.rs:56-74; openpbr.rs:1138-1158.
+ * None iff the material is Emissive or the view direction is below the surface — never because of wi. */
+int crt_material_eval_n(const CrtMaterial *d_materials, size_t n_materials, const CrtShadeQuery *d_queries, size_t n,
+                        CrtBsdfEval *d_out, void *stream);
+/* Material::emitted_directional(cos_theta_o) -> Vec3A                          material.rs:112-115; openpbr.rs:1211-1218
+ * (emission seen through the coat); Emissive: its radiance (emissive.rs:25-28). d_rgb: 3 floats per query. */
+int crt_material_emitted_n(const CrtMaterial *d_materials, size_t n_materials, const CrtShadeQuery *d_queries, size_t n,
+                           float *d_rgb, void *stream);
+/* Light::sample_li(from, u, v) -> Option<LightSample>                           light.rs:126, AreaLight :191-204 (sphere
+ * :27-36, rect :69-81), DistantLight :285-298, uniform DomeLight :358-383. */
+int crt_light_sample_n(const CrtLight *d_lights, size_t n_lights, const CrtLightQuery *d_queries, size_t n,
+                       CrtLightSample *d_out, void *stream);
+/* Light::pdf_at_point(from, light_point) -> f32                                 light.rs:132, AreaLight :206-208 ->
+ * solid_angle_pdf :180-187; 0 for lights at infinity (the trait's default). d_pdf: one float per query. */
+int crt_light_pdf_n(const CrtLight *d_lights, size_t n_lights, const CrtLightQuery *d_queries, size_t n, float *d_pdf,
+                    void *stream);
+/* Light::escaped(from, direction) -> Option<(radiance, pdf)>                    light.rs:141-146, :300-303, :385-388;
+ * None (some = 0) for area lights and for directions the light does not cover. out.direction = the query's. */
+int crt_light_escaped_n(const CrtLight *d_lights, size_t n_lights, const CrtLightQuery *d_queries, size_t n,
+                        CrtLightSample *d_out, void *stream);
 
 enum { CRT_STRATEGY_POWER = 0, CRT_STRATEGY_BALANCE = 1, CRT_STRATEGY_LIGHT = 2, CRT_STRATEGY_BSDF = 3 }; /* tracer.rs:63-75 */
 enum { CRT_FILTER_BOX = 0, CRT_FILTER_TRIANGLE = 1 };                                                       /* filter.rs:27-41 */

@@ -922,3 +922,80 @@ float ora_t_rnd1(uint32_t pattern, uint32_t index) {
   OraSampler s = {pattern, index};
   return ora_draw_rnd1(s);
 }
+
+/* ------------------------------------------------------------------ */
+/* Batched drivers over the trait-level functions above, one call per  */
+/* record: the checker's side of tests/test_gpu_shading_seam.py and of */
+/* tests/host_shade/compare_oracle.cpp. Record layouts = include/crt.h */
+/* (CrtShadeQuery 80 B, CrtScatterSample 48 B, CrtBsdfEval 32 B,       */
+/* CrtLightQuery 48 B, CrtLightSample 48 B), restated here.            */
+/* ------------------------------------------------------------------ */
+typedef struct {
+  float ray_dir[3]; uint32_t material; float p[3]; float t; float normal[3]; uint32_t front_face;
+  float wi[3]; float cos_theta_o; uint32_t sampler_pattern, sampler_index; uint32_t pad[2];
+} OraShadeQuery;
+typedef struct { float origin[3]; uint32_t some; float dir[3]; float pdf; float value[3]; uint32_t flags; } OraScatterOut;
+typedef struct { float value[3]; float pdf; uint32_t some; uint32_t pad[3]; } OraEvalOut;
+typedef struct { float from[3]; uint32_t light; float u, v; uint32_t pad[2]; float point[3]; uint32_t pad2; } OraLightQuery;
+typedef struct { float direction[3]; float distance; float radiance[3]; float pdf; uint32_t some; uint32_t pad[3]; } OraLightOut;
+_Static_assert(sizeof(OraShadeQuery) == 80 && sizeof(OraScatterOut) == 48 && sizeof(OraEvalOut) == 32, "crt.h layouts");
+_Static_assert(sizeof(OraLightQuery) == 48 && sizeof(OraLightOut) == 48, "crt.h layouts");
+
+static OraHitRecord query_rec(const OraShadeQuery *q) {
+  OraHitRecord rec;
+  rec.p = c3(q->p); rec.normal = c3(q->normal); rec.t = q->t; rec.front_face = q->front_face != 0;
+  return rec;
+}
+static void put3(float dst[3], v3 a) { dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; }
+
+void ora_t_scatter_n(const OraMaterial *mats, size_t n_mats, const OraShadeQuery *qs, size_t n, OraScatterOut *out) {
+  for (size_t i = 0; i < n; i++) { /* Material::scatter_importance, material.rs:40-45 */
+    memset(&out[i], 0, sizeof out[i]);
+    if (qs[i].material >= n_mats) continue;
+    OraHitRecord rec = query_rec(&qs[i]);
+    OraSampler dom = {qs[i].sampler_pattern, qs[i].sampler_index};
+    OraScatter sc;
+    if (!ora_mat_scatter(&mats[qs[i].material], c3(qs[i].ray_dir), &rec, dom, &sc)) continue;
+    put3(out[i].origin, sc.origin); put3(out[i].dir, sc.dir); put3(out[i].value, sc.value);
+    out[i].some = 1; out[i].pdf = sc.pdf; out[i].flags = (sc.delta ? 1u : 0u) | (sc.medium ? 2u : 0u);
+  }
+}
+void ora_t_eval_n(const OraMaterial *mats, size_t n_mats, const OraShadeQuery *qs, size_t n, OraEvalOut *out) {
+  for (size_t i = 0; i < n; i++) { /* Material::eval, material.rs:56-74 */
+    memset(&out[i], 0, sizeof out[i]);
+    if (qs[i].material >= n_mats) continue;
+    OraHitRecord rec = query_rec(&qs[i]);
+    v3 value; float pdf;
+    if (!ora_mat_eval(&mats[qs[i].material], c3(qs[i].ray_dir), &rec, c3(qs[i].wi), &value, &pdf)) continue;
+    put3(out[i].value, value); out[i].pdf = pdf; out[i].some = 1;
+  }
+}
+void ora_t_emitted_n(const OraMaterial *mats, size_t n_mats, const OraShadeQuery *qs, size_t n, float *rgb) {
+  for (size_t i = 0; i < n; i++) { /* Material::emitted_directional, material.rs:112-115 */
+    v3 e = v3_splat(0.0f);
+    if (qs[i].material < n_mats) e = ora_mat_emitted_directional(&mats[qs[i].material], qs[i].cos_theta_o);
+    put3(rgb + 3 * i, e);
+  }
+}
+void ora_t_light_sample_n(const OraLight *ls, size_t n_ls, const OraLightQuery *qs, size_t n, OraLightOut *out) {
+  for (size_t i = 0; i < n; i++) { /* Light::sample_li, light.rs:126 */
+    memset(&out[i], 0, sizeof out[i]);
+    OraLightSample s;
+    if (qs[i].light >= n_ls || !ora_light_sample_li(&ls[qs[i].light], c3(qs[i].from), qs[i].u, qs[i].v, &s)) continue;
+    put3(out[i].direction, s.direction); out[i].distance = s.distance; put3(out[i].radiance, s.radiance);
+    out[i].pdf = s.pdf; out[i].some = 1;
+  }
+}
+void ora_t_light_pdf_n(const OraLight *ls, size_t n_ls, const OraLightQuery *qs, size_t n, float *pdf) {
+  for (size_t i = 0; i < n; i++) /* Light::pdf_at_point, light.rs:132 */
+    pdf[i] = qs[i].light < n_ls ? ora_light_pdf_at_point(&ls[qs[i].light], c3(qs[i].from), c3(qs[i].point)) : 0.0f;
+}
+void ora_t_light_escaped_n(const OraLight *ls, size_t n_ls, const OraLightQuery *qs, size_t n, OraLightOut *out) {
+  for (size_t i = 0; i < n; i++) { /* Light::escaped, light.rs:141 */
+    memset(&out[i], 0, sizeof out[i]);
+    v3 rad; float pdf;
+    if (qs[i].light >= n_ls || !ora_light_escaped(&ls[qs[i].light], c3(qs[i].point), &rad, &pdf)) continue;
+    put3(out[i].direction, c3(qs[i].point)); out[i].distance = INFINITY; put3(out[i].radiance, rad);
+    out[i].pdf = pdf; out[i].some = 1;
+  }
+}

@@ -241,3 +241,65 @@ def test_instance_heavy_images_carry_no_direct_word_the_engine_was_told_not_to_r
             assert s["leaf_words_plain"] > 0
         else:
             assert s["direct_leaves"] == 1 and s["leaf_words_direct_instance"] == 0 and s["leaf_words_direct_index"] > 0
+
+
+_ENGINE_KNOBS = ("CRT_DIRECT_LEAVES", "CRT_DIRECT_INST", "CRT_WIDE", "CRT_POOL_STACK_RT", "CRT_COLD")
+
+
+def test_every_knob_combination_selects_an_engine_that_can_decode_the_image(crt, monkeypatch):
+    """The engine-vs-image class, closed in one place (crt_internal.h, select_engine): rounds 2 and 3 each lost a GPU box
+    to a traversal-engine instance meeting an image form it was not built for (profiles/README.md, "The r02f abort",
+    "The r03w fault": direct child words read by the four-wave kernels, which carry no direct-leaf engine). For every
+    combination of the A/B knobs that shape the image or the choice, on the six scene recipes, what a launch in this
+    process would select (want_wide = -2) decodes every child word of the image and keeps every cold field it needs —
+    crt_scene_engine_select checks the selection against a census of the flattened image, on the host."""
+    import itertools
+    built = {name: make(crt) for name, (make, _) in scenes.ALL.items()}
+    values = {"CRT_DIRECT_LEAVES": (None, "0", "1"), "CRT_DIRECT_INST": (None, "0"), "CRT_WIDE": (None, "0", "1"),
+              "CRT_POOL_STACK_RT": (None, "3", "6", "10"), "CRT_COLD": (None, "7")}
+    n_wide = n_direct = 0
+    for combo in itertools.product(*(values[k] for k in _ENGINE_KNOBS)):
+        for k, v in zip(_ENGINE_KNOBS, combo):
+            monkeypatch.delenv(k, raising=False) if v is None else monkeypatch.setenv(k, v)
+        env = dict(zip(_ENGINE_KNOBS, combo))
+        for name, scene in built.items():
+            sel = scene.engine_select(-2)  # raises on a selection the image census contradicts
+            img = scene.image_check()
+            words = img["leaf_words_direct_index"] + img["leaf_words_direct_instance"]
+            assert sel["direct_words"] == words, (name, env)
+            if words or img["direct_leaves"]:
+                assert sel["wide"] == 0 and sel["direct"] == 1, (name, env)
+                with pytest.raises(crt.CrtError) as refused:  # asked for outright: refused, never launched
+                    scene.engine_select(1)
+                assert refused.value.code == -5
+            if sel["wide"]:
+                assert words == 0 and sel["lds_stack"] == 3 and sel["window"] == 26, (name, env)
+            else:
+                assert sel["lds_stack"] in (6, 10) and sel["window"] == (16 if sel["lds_stack"] == 10 else 72), (name, env)
+            assert sel["cold"] & ~sel["ext_cold"] == 0 and sel["cold"] & ~sel["path_cold"] == 0, (name, env)
+            if env["CRT_WIDE"] == "1" and not img["direct_leaves"]:  # (the flag, not the census: select_engine is conservative)
+                assert sel["wide"] == 1, (name, env)
+            if env["CRT_WIDE"] == "0":
+                assert sel["wide"] == 0, (name, env)
+            n_wide += sel["wide"]
+            n_direct += sel["direct"]
+    assert n_wide > 0 and n_direct > 0  # both kinds of instance were exercised
+
+
+def test_a_small_flat_scene_with_direct_leaves_forced_never_selects_the_four_wave_kernels(crt, monkeypatch):
+    """The third way in the round-3 review found: CRT_DIRECT_LEAVES=1 on a small flat scene (cornellbox: packet-free
+    leaves of its two instance placements) writes direct words while the old wide_split — pool_stack, packets and node
+    count only — still chose the four-wave kernels. Same for CRT_POOL_STACK_RT=6 on an instance-heavy image."""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes", "cornellbox.usda")
+    scene, _mats, _protos = crt.usda.build_world(crt.usda.load(path, 64, 36), crt, crt.default_material)
+    assert scene.engine_select(-2)["wide"] == 1 and scene.image_check()["direct_leaves"] == 0  # the shipped default
+    monkeypatch.setenv("CRT_DIRECT_LEAVES", "1")
+    sel, img = scene.engine_select(-2), scene.image_check()
+    assert img["direct_leaves"] == 1 and img["leaf_words_direct_instance"] + img["leaf_words_direct_index"] > 0
+    assert sel["wide"] == 0 and sel["direct"] == 1
+    monkeypatch.delenv("CRT_DIRECT_LEAVES")
+    monkeypatch.setenv("CRT_POOL_STACK_RT", "6")
+    make, _ = scenes.ALL["instances"]  # 125 placements: direct leaves by default, 6 + 72 split forced
+    s = make(crt)
+    sel = s.engine_select(-2)
+    assert s.image_check()["direct_leaves"] == 1 and sel["wide"] == 0 and sel["direct"] == 1 and sel["lds_stack"] == 6
