@@ -61,6 +61,10 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1; gloo (CPU tensors, ranks may share a GPU) rehearses the N > 1 path on a 1-GPU box")
     ap.add_argument("--cpu-reps", type=int, default=3, help="the CPU baseline is the best of this many runs (BASELINE.md §3: min of 3)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the other BASELINE configurations that follow the headline at N=1 (other_configs)")
+    ap.add_argument("--other-configs-scale", type=int, default=1,
+                    help="divide the other configurations' width and height by this and their spp by its square (tests)")
     ap.add_argument("--dump-frame", default=None, help="rank 0 writes the gathered frame ([height*width, 3] float32, .npy) here")
     args = ap.parse_args()
 
@@ -111,18 +115,11 @@ def main():
         torch.cuda.synchronize()
 
     # A part with less free HBM than the batch needs (the default shape holds 174 GB of path state) halves the batch until
-    # it fits; the shape actually run is what the line reports (config.spp_per_step).
+    # it fits; the shape actually run is what the line reports (config.spp_per_step). N > 1: every rank runs the smallest
+    # shape any rank settled on.
     requested = args.spp_per_step
-    while True:
-        try:
-            r.render_samples(0, spp_step, stream)
-            torch.cuda.synchronize()
-            break
-        except crt.CrtError:
-            if args.spp_per_step <= 1:
-                raise
-            args.spp_per_step //= 2
-            spp_step = args.spp_per_step * world
+    args.spp_per_step = fit_batch(crt, r, args.spp_per_step, world, stream, dist, coll)
+    spp_step = args.spp_per_step * world
     sample = 0
     for _ in range(args.warmup):
         r.render_samples(sample, spp_step, stream)
@@ -197,7 +194,7 @@ def main():
                                               traffic_scale=1.0 / lanes)
     dominant = max(kernels, key=lambda k: kernels[k]["total_ms"]) if kernels else None
     # the other pipeline on the same workload, 2 untimed steps: per-stage split of a fused step / the fused kernel's time.
-    # The timed renderer's buffers (87 GB at the default shape) are released first.
+    # The timed renderer's buffers (174 GB at the default shape) are released first.
     settings_depth = r.settings.max_depth
     n_pix = r.n_pix
     del r
@@ -210,6 +207,7 @@ def main():
         saved_l = os.environ.get("CRT_LANES")
         try:
             os.environ["CRT_LANES"] = "1"
+            r1 = None
             r1, _ = crt.load_usda(path, args.width, args.height, args.depth, rank=rank, world=world)
             r1.render_samples(0, spp_step, stream)
             torch.cuda.synchronize()
@@ -224,10 +222,10 @@ def main():
                     serial[names[cls]] = _roofline_entry(names[cls], per_step * 2 / p1[cls]["launches"], p1[cls]["ms"], p1[cls]["launches"], 2,
                                                          workload_key, world)
             serial_ms = {k: round(v["ms"] / 2, 3) for k, v in p1.items()}
-            del r1
         except crt.CrtError as e:
             serial = None
         finally:
+            r1 = None  # its whole-batch buffer (174 GB at the default shape) must be gone before the next renderer is built
             if saved_l is None:
                 os.environ.pop("CRT_LANES", None)
             else:
@@ -236,6 +234,7 @@ def main():
     try:
         os.environ["CRT_FUSED"] = "0" if fused else "1"
         os.environ["CRT_LANES"] = "1"  # one lane: the other pipeline's launches alone on the chip, comparable with `serial`
+        r2 = None
         r2, _ = crt.load_usda(path, args.width, args.height, args.depth, rank=rank, world=world)
         r2.render_samples(0, spp_step, stream)
         torch.cuda.synchronize()
@@ -250,10 +249,10 @@ def main():
                 stage["extend_algorithmic_gb_s"] = round(ext.algorithmic_bytes() / (p2["extend"]["ms"] / 2 * 1e-3) / 1e9, 1)
             else:
                 other = {"fused_k_path_ms_per_step": round(p2["extend"]["ms"] / 2, 3), "other": round(p2["other"]["ms"] / 2, 3)}
-        del r2
     except crt.CrtError as e:  # the probe is informational: a box with less free HBM still prints the line
         other = {"error": str(e)}
     finally:
+        r2 = None
         for k, v in saved.items():
             if v is None:
                 os.environ.pop(k, None)
@@ -290,9 +289,23 @@ def main():
         "other_pipeline": other,
     })
 
-    cpu = None
+    cpu = cpu_all = None
     if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
         cpu = _cpu_baseline(crt, desc, args)
+        # ... and on EVERY hardware thread this process may run on, as the reference's Rayon pool would take them
+        # (tracer.rs:424-459); 4x the samples so the sample is still seconds of work
+        cpu_all = _cpu_baseline(crt, desc, args, all_cores=True)
+    # The other BASELINE configurations on the same clock (N = 1, headline scene only): after the headline, 2 timed steps
+    # each of the reference's stress scene, configs[4]'s own file at its own 3840x2160, configs[3] and configs[2] at 1080p.
+    others = None
+    if world == 1 and not args.no_other_configs and args.scene == "cornellbox":
+        others = []
+        k = max(args.other_configs_scale, 1)
+        for scene, w, h, spp in [(sc, max(w // k, 16), max(h // k, 16), max(spp // (k * k), 2)) for sc, w, h, spp in OTHER_CONFIGS]:
+            try:
+                others.append(other_config(crt, torch, scene, w, h, spp, stream))
+            except Exception as e:  # noqa: BLE001  (informational: the headline still prints)
+                others.append({"workload": "%s %dx%d %dspp" % (scene, w, h, spp), "error": "%s: %s" % (type(e).__name__, e)})
 
     out = {
         "metric": "Mray/s (closest-hit + shadow queries) of the path-tracing integrator",
@@ -331,10 +344,90 @@ def main():
         },
         "roofline": roofline,
         "cpu_baseline": cpu,
+        "cpu_baseline_all_cores": cpu_all,
+        "other_configs": others,
     }
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+# (scene, width, height, spp per step): BASELINE.json configs[2..4] at their own resolutions + the reference's stress
+# scene (scripts/gen_stress_scene.py, docs/simd.md:221) — the path-traced workloads that call `occluded`.
+OTHER_CONFIGS = [("stress", 1920, 1080, 256), ("PointInstancedMedCity", 3840, 2160, 128), ("veach_mis", 1920, 1080, 512),
+                 ("openpbr_showcase", 1920, 1080, 512)]
+
+
+def fit_batch(crt, r, spp_per_step, world, stream, dist=None, coll="cuda"):
+    """One untimed batch of spp_per_step * world samples; while the renderer cannot allocate it (CrtError), half of it.
+    Returns the per-GPU-share spp that fits — with N > 1 the smallest any rank settled on, so every rank times the same
+    shape. The probe's samples are cleared from the film and the counters."""
+    import torch
+    while True:
+        try:
+            r.render_samples(0, spp_per_step * world, stream)
+            torch.cuda.synchronize()
+            break
+        except crt.CrtError:
+            if spp_per_step <= 1:
+                raise
+            spp_per_step //= 2
+    if dist is not None:
+        t = torch.tensor([spp_per_step], dtype=torch.int64, device=coll)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        spp_per_step = int(t.item())
+    r.clear(stream)
+    torch.cuda.synchronize()
+    return spp_per_step
+
+
+def other_config(crt, torch, scene, width, height, spp, stream, steps=2):
+    """One of the other configurations: scene import and commit untimed, one untimed batch (which also sizes the batch to
+    the free HBM), then `steps` timed batches bracketed by synchronize; the dominant kernel's roofline tier from the
+    committed PMC passes of this build, priced on the timed region's HIP events and the stats build's counters."""
+    path = crt.scene_path(scene)
+    t_imp = time.perf_counter()
+    r, _desc = crt.load_usda(path, width, height, None)
+    import_s = time.perf_counter() - t_imp
+    spp = fit_batch(crt, r, spp, 1, stream)
+    r.profile(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        r.render_samples(k * spp, spp, stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    st, prof, pipe, lanes = r.stats(), r.profile_read(), r.pipeline(), r.lanes()
+    r.profile(False)
+    ext, sh = r.render_samples_stats(0, spp, stream)
+    depth = r.settings.max_depth
+    r = None
+    alg = {"extend": ext.algorithmic_bytes(), "shadow": sh.algorithmic_bytes(), "shade": 352 * (st.vertices // steps)}
+    if pipe["fused"]:
+        alg = {"extend": alg["extend"] + alg["shadow"] + alg["shade"]}
+    names = {"extend": "k_path" if pipe["fused"] else "k_extend", "shade": "k_shade", "shadow": "k_shadow"}
+    key = "%s %dx%d %dspp" % (scene, width, height, spp)
+    kernels = {}
+    for cls, per_step in alg.items():
+        if prof[cls]["launches"] and prof[cls]["ms"] > 0:
+            kernels[names[cls]] = _roofline_entry(names[cls], per_step * steps / prof[cls]["launches"], prof[cls]["ms"],
+                                                  prof[cls]["launches"], steps, key, 1, traffic_scale=1.0 / lanes)
+    dom = max(kernels, key=lambda k: kernels[k]["total_ms"]) if kernels else None
+    e = kernels.get(dom, {})
+    total = st.total_rays()
+    return {
+        "workload": "%s %dx%d, %d spp per step, depth %d" % (scene, width, height, spp, depth),
+        "value": round(total / elapsed / 1e6, 2), "unit": "Mray/s", "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps,
+        "closest_hit": int(st.closest_hit), "shadow_rays": int(st.shadow_rays),
+        "pipeline": "fused" if pipe["fused"] else ("per-stage, %d workgroups per CU in the traversal kernels" % (4 if pipe["wide"] else 3)),
+        "lanes": lanes, "import_and_commit_s": round(import_s, 2),
+        "roofline": {"kernel": dom, "bound": e.get("bound"), "tier": e.get("tier"), "frac": e.get("frac"),
+                     "achieved": e.get("achieved"), "peak": e.get("peak"), "unit": "GB/s",
+                     "hbm_measured_frac": e.get("hbm_measured_frac"), "l2_hit": e.get("l2_hit"), "traffic": e.get("traffic"),
+                     "avg_launch_ms": e.get("avg_launch_ms"), "launches": e.get("launches"), "pmc_source": e.get("pmc_source"),
+                     # lanes overlap their launches: a launch's own duration includes the time it shares the chip
+                     "timing": "HIP events of the timed region (%d lane%s)" % (lanes, "" if lanes == 1 else "s, overlapping")},
+    }
 
 
 L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md: L2 aggregate ~34.5 TB/s (eight XCDs x 4 MiB)
@@ -430,7 +523,14 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r03_pmc_bench.json")
+def _pmc_profile_path():
+    """The committed per-kernel PMC summary to read: the newest profiles/r*_pmc_bench.json (named per round)."""
+    d = os.path.join(ROOT, "profiles")
+    names = sorted(n for n in os.listdir(d) if n.startswith("r") and n.endswith("_pmc_bench.json")) if os.path.isdir(d) else []
+    return os.path.join(d, names[-1]) if names else os.path.join(d, "r04_pmc_bench.json")
+
+
+PMC_PROFILE = _pmc_profile_path()
 
 
 def _pmc_for(workload_key, kernel):
@@ -457,9 +557,11 @@ def _pmc_for(workload_key, kernel):
     return e, "%s (git %s)" % (os.path.relpath(PMC_PROFILE, ROOT), prof.get("git_commit", "?"))
 
 
-def _cpu_baseline(crt, desc, args):
-    """The oracle (kind 'port': CPU restatement of the reference's algorithm, all host cores, 16x16 tiles as
-    tracer.rs:424-459) on a bounded sample of the same workload: the full frame at --cpu-spp samples."""
+def _cpu_baseline(crt, desc, args, all_cores=False):
+    """The oracle (kind 'port': CPU restatement of the reference's algorithm, 16x16 tiles on worker threads as
+    tracer.rs:424-459) on a bounded sample of the same workload: the full frame at --cpu-spp samples, on this box's
+    16-core share — or, all_cores, on every hardware thread the process may run on (what the reference's Rayon pool
+    would take) at four times the samples."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import ora_world
     try:
@@ -467,11 +569,14 @@ def _cpu_baseline(crt, desc, args):
     except Exception:
         avail = os.cpu_count() or 1
     cores = args.cpu_threads if args.cpu_threads > 0 else min(avail, 16)  # a 1-GPU box's CPU share is 16 cores
+    cpu_spp = args.cpu_spp
+    if all_cores:
+        cores, cpu_spp = avail, args.cpu_spp * 4
     o = ora_world.OracleRenderer(desc, crt.usda, max_depth=args.depth, forward=0)
     times = []
     for _ in range(max(args.cpu_reps, 1)):  # min of N render-phase times (scripts/bench_scenes.sh:33 convention)
         t0 = time.perf_counter()
-        _, st = o.render(args.cpu_spp, threads=cores)
+        _, st = o.render(cpu_spp, threads=cores)
         times.append(time.perf_counter() - t0)
     dt = min(times)
     model = ""
@@ -490,7 +595,7 @@ def _cpu_baseline(crt, desc, args):
         "host_affinity": avail,  # hardware threads this process may run on; `cores` of them were used
         "kind": "port",
         "sample": "%dx%d full frame at %d spp (%d rays), best of %d runs (%s s), reference-order estimator, host: %s" % (
-            args.width, args.height, args.cpu_spp, st.total_rays(), len(times), " / ".join("%.1f" % t for t in times), model),
+            args.width, args.height, cpu_spp, st.total_rays(), len(times), " / ".join("%.1f" % t for t in times), model),
     }
 
 

@@ -164,6 +164,8 @@ ABI_SYMBOLS = [
     "crt_scene_engine_select",
     "crt_material_scatter_n", "crt_material_eval_n", "crt_material_emitted_n", "crt_light_sample_n", "crt_light_pdf_n",
     "crt_light_escaped_n",
+    "crt_shard_padded_count", "crt_gather_plan_new", "crt_gather_plan_free", "crt_gather_plan_padded_count",
+    "crt_gather_plan_assemble",
 ]
 
 _lib = None
@@ -255,6 +257,15 @@ def lib():
             L.crt_renderer_shade_class_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.crt_renderer_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         L.crt_render_samples_stats.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.POINTER(CrtTravStats)]
+    if hasattr(L, "crt_gather_plan_new"):
+        L.crt_shard_padded_count.restype = C.c_size_t
+        L.crt_shard_padded_count.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+        L.crt_gather_plan_new.restype = vp
+        L.crt_gather_plan_new.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+        L.crt_gather_plan_free.argtypes = [vp]
+        L.crt_gather_plan_padded_count.restype = C.c_size_t
+        L.crt_gather_plan_padded_count.argtypes = [vp]
+        L.crt_gather_plan_assemble.argtypes = [vp, vp, vp, vp]
     for name in ("crt_material_scatter_n", "crt_material_eval_n", "crt_material_emitted_n", "crt_light_sample_n",
                  "crt_light_pdf_n", "crt_light_escaped_n"):  # the shading seam (shading.py)
         if hasattr(L, name):

@@ -358,8 +358,8 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
           // Stack image after this node, bottom to top. Ordered traversal: inner lanes far to near, then leaf
           // lanes far to near on top, so they pop first and near-first — the reference's "leaf lanes now, near
           // first; inner lanes pushed far to near" (bvh.rs:488-505) after its stable insertion sort of the hit
-          // lanes by entry distance (bvh.rs:472-486: equal keys keep lane order). Any-hit: the hit lanes in lane
-          // order (bvh.rs:596-606). Every entry's final position follows from the six pairwise "is nearer"
+          // lanes by entry distance (bvh.rs:472-486: equal keys keep lane order). Any-hit: leaf lanes first, in lane
+          // order, then the inner lanes from the highest down (bvh.rs:596-606). Every entry's final position follows from the six pairwise "is nearer"
           // relations, so the entries are stored with independent predicated writes — no sorting network — and
           // the top one, the entry the ray visits next, stays in a register.
           uint32_t on[4], lf4[4], pos[4];
@@ -367,8 +367,19 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
           for (int i = 0; i < 4; i++) { on[i] = ent[i] != kInvalid ? 1u : 0u; lf4[i] = (on[i] && (ent[i] & kLeafTag)) ? 1u : 0u; }
           uint32_t n_tot;
           if (ANY) {
-            pos[0] = 0; pos[1] = on[0]; pos[2] = on[0] + on[1]; pos[3] = on[0] + on[1] + on[2];
-            n_tot = pos[3] + on[3];
+            // hit_any (bvh.rs:596-606) tests a node's leaf lanes AT ONCE, in lane order, and pushes its inner lanes in
+            // lane order (the last one pops first): inner lanes at the bottom in lane order, leaf lanes above them in
+            // REVERSE lane order, so lane 0's leaf is the next entry, then lane 1's ..., then the highest inner lane.
+            // (Rounds 1-3 stacked all hit lanes in lane order — the highest lane first, leaf or not: same answers, but
+            // 32 % more node visits on the stress scene's shadow rays than the reference makes; the any-hit counters
+            // now equal the oracle's, tests/test_gpu_stress.py.)
+            const uint32_t in0 = on[0] & ~lf4[0], in1 = on[1] & ~lf4[1], in2 = on[2] & ~lf4[2], in3 = on[3] & ~lf4[3];
+            const uint32_t n_in = in0 + in1 + in2 + in3;
+            pos[0] = lf4[0] ? n_in + lf4[1] + lf4[2] + lf4[3] : 0u;
+            pos[1] = lf4[1] ? n_in + lf4[2] + lf4[3] : in0;
+            pos[2] = lf4[2] ? n_in + lf4[3] : in0 + in1;
+            pos[3] = lf4[3] ? n_in : in0 + in1 + in2;
+            n_tot = on[0] + on[1] + on[2] + on[3];
           } else {
             // For every pair i < j: x = 1 iff lane j ends up below lane i. Same kind: the farther one is below,
             // and lane i is the nearer one iff key_i <= key_j (stable: equal keys keep lane order, bvh.rs:472-486).

@@ -22,10 +22,10 @@ def shard_pixels(width, height, rank, world):
 
 
 def padded_count(width, height, world):
-    """Common per-rank buffer length for the gather: the largest shard, rounded up to a 256-pixel multiple."""
-    tx, ty = (width + 15) // 16, (height + 15) // 16
-    tiles = (tx * ty + world - 1) // world
-    return ((tiles * 256 + 255) // 256) * 256
+    """Common per-rank buffer length for the gather: the largest shard, rounded up to a 256-pixel multiple
+    (C ABI: crt_shard_padded_count)."""
+    from . import lib
+    return int(lib().crt_shard_padded_count(width, height, world))
 
 
 class GatherPlan:
@@ -40,6 +40,23 @@ class GatherPlan:
         self.send = torch.zeros(self.n_max * 3, dtype=torch.float32, device=device)
         self.recv = torch.empty(world * self.n_max * 3, dtype=torch.float32, device=device) if world > 1 else self.send
         self.frame = torch.zeros(height * width, 3, dtype=torch.float32, device=device)
+        # buffers in HBM: the frame is assembled by the library's own kernel (crt_gather_plan_assemble) — what a host
+        # without torch calls after its own collective; CPU tensors (the gloo tests) take the indexed stores below
+        self._plan = None
+        if torch.device(device).type == "cuda":
+            from . import lib
+            self._plan = lib().crt_gather_plan_new(width, height, world)
+            if not self._plan:
+                raise RuntimeError("crt_gather_plan_new failed: " + lib().crt_last_error().decode())
+            assert lib().crt_gather_plan_padded_count(self._plan) == self.n_max
+
+    def __del__(self):
+        try:
+            if self._plan:
+                from . import lib
+                lib().crt_gather_plan_free(self._plan)
+        except Exception:
+            pass
 
     def gather(self, film_local, dist=None, dst=None):
         """film_local: [n_owned, 3] of this rank (same device as the plan). ONE collective, then one indexed store
@@ -56,6 +73,11 @@ class GatherPlan:
                 dist.gather(self.send, parts, dst=dst)
                 if not mine:
                     return None
+        if self._plan:
+            from . import lib, _check, _stream_ptr
+            _check(lib().crt_gather_plan_assemble(self._plan, self.recv.data_ptr(), self.frame.data_ptr(), _stream_ptr(None)),
+                   "crt_gather_plan_assemble")
+            return self.frame
         recv = self.recv.reshape(self.world, self.n_max, 3)
         for r in range(self.world):
             self.frame[self.idx[r]] = recv[r, : self.idx[r].numel()]

@@ -1,5 +1,8 @@
 """Synthetic scenes built in code (SceneDesc, like the USDA reader produces).
 
+`big`: the out-of-cache path-traced workload (27 tessellated spheres, 7.08 M triangles at the default tessellation, a
+rect light) on which the traversal kernels are HBM-bound inside the integrator — see its docstring.
+
 `city`: the stand-in for BASELINE config 5. `PointInstancedMedCity.usd` is a binary USDC crate (LZ4 sections) that
 nothing here can read, so the instancing-heavy workload it stands for — thousands of placements of
 a few prototype meshes under one top-level BVH, every camera ray descending into instances — is generated instead,
@@ -96,6 +99,67 @@ def city(width=640, height=360, side=64, seed=0x2545F491, max_depth=8):
     lookat = np.array([0.0, 0.0, 0.0], dtype=np.float32)
     d.camera = dict(lookfrom=lookfrom, lookat=lookat, vup=np.array([0, 1, 0], dtype=np.float32), vfov_deg=f32(40.0),
                     aspect=f32(f32(width) / f32(height)), aperture=f32(0.0), focus_dist=f32(10.0))
+    d.settings = dict(usda.DEFAULTS, strategy="power", filter="triangle", filter_radius=1.0, width=width, height=height,
+                      max_depth=max_depth)
+    return d
+
+
+
+def _uv_sphere(center, radius, segs, rings):
+    """The reference probe's UV-sphere topology (crates/crust-rt/examples/ray_throughput.rs:18-48), vectorised: values are
+    numpy's sin / cos in f64 rounded to f32 — the SAME arrays reach the device library and the oracle, so parity holds
+    whatever the last bit of a vertex is."""
+    r = np.arange(rings + 1, dtype=np.float64)[:, None] / rings * np.pi
+    t = np.arange(segs + 1, dtype=np.float64)[None, :] / segs * 2.0 * np.pi
+    d = np.stack([np.sin(r) * np.cos(t), np.cos(r) * np.ones_like(t), np.sin(r) * np.sin(t)], axis=-1).reshape(-1, 3)
+    v = (np.asarray(center, dtype=np.float64) + radius * d).astype(np.float32)
+    row = segs + 1
+    rr, ss = np.meshgrid(np.arange(rings), np.arange(segs), indexing="ij")
+    a, b, c, e = rr * row + ss, rr * row + ss + 1, (rr + 1) * row + ss + 1, (rr + 1) * row + ss
+    idx = np.stack([np.stack([a, b, c], -1), np.stack([a, c, e], -1)], axis=2).reshape(-1, 3).astype(np.uint32)
+    return v, idx
+
+
+def big(width=640, height=360, side=512, max_depth=6):
+    """SYNTHETIC (generated in code, not a reference file; labelled so wherever it is reported). The out-of-cache
+    path-traced workload: the reference's `tri_spheres` probe layout (ray_throughput.rs:50-65: 27 UV spheres on a 3x3x3
+    grid at 2.5 spacing) at `side` x `side`/2 quads per sphere — 512 -> 7 077 888 triangles, a 1.03 GB device image, four
+    times the Infinity Cache — on a floor under a 10 x 10 RectLight, seen from outside the cluster. Diffuse and rough-metal
+    looks only (simple material table, flat shading: the leanest kernel instances), depth 6: camera rays, incoherent bounce
+    rays between the spheres and one shadow ray per vertex all traverse a tree that does not fit any cache — the
+    north_star's ">= 40 % of HBM peak in the traversal kernel" is physically reachable only on a scene like this
+    (SURVEY §8d). side = 128 (442 368 triangles) is the size the parity tests render against the oracle."""
+    d = usda.SceneDesc()
+    looks = [
+        {"base_color": (0.75, 0.25, 0.20), "specular_weight": 0.0},
+        {"base_color": (0.25, 0.60, 0.30), "specular_weight": 0.0},
+        {"base_color": (0.25, 0.35, 0.75), "specular_weight": 0.5, "specular_roughness": 0.4},
+        {"base_color": (0.90, 0.85, 0.70), "base_metalness": 1.0, "specular_roughness": 0.35},
+        {"base_color": (0.80, 0.80, 0.80), "specular_weight": 0.0},
+    ]
+    k = 0
+    for x in (-1, 0, 1):
+        for y in (-1, 0, 1):
+            for z in (-1, 0, 1):
+                v, i = _uv_sphere((2.5 * x, 2.5 * y, 2.5 * z), 1.0, side, side // 2)
+                d.geoms.append(dict(kind="mesh", verts=v, idx=i, mask=0xFFFFFFFF, material=dict(looks[k % len(looks)]),
+                                    name="ball_%d" % k))
+                k += 1
+    g = np.array([(-14, -3.9, -14), (14, -3.9, -14), (14, -3.9, 14), (-14, -3.9, 14)], dtype=np.float32)
+    d.geoms.append(dict(kind="mesh", verts=g, idx=np.array([(0, 2, 1), (0, 3, 2)], np.uint32), mask=0xFFFFFFFF,
+                        material={"base_color": (0.6, 0.6, 0.58), "specular_weight": 0.0}, name="floor"))
+    o = np.array([-5.0, 7.5, -5.0], dtype=np.float32)
+    eu, ev = np.array([10.0, 0.0, 0.0], dtype=np.float32), np.array([0.0, 0.0, 10.0], dtype=np.float32)
+    rad = (9.0, 8.6, 8.0)
+    gid = len(d.geoms)
+    quad = np.stack([o, o + eu, o + eu + ev, o + ev]).astype(np.float32)
+    d.geoms.append(dict(kind="mesh", verts=quad, idx=np.array([(0, 1, 2), (0, 2, 3)], np.uint32), mask=0xFFFFFFFF & ~2,
+                        material={"_preset": "emissive", "emission_color": rad}, name="light"))
+    d.lights.append(dict(kind="rect", geom_id=gid, radiance=np.array(rad, np.float32), origin=o, edge_u=eu, edge_v=ev,
+                         normal=np.array([0, -1, 0], np.float32)))
+    d.camera = dict(lookfrom=np.array([6.5, 3.5, 11.0], np.float32), lookat=np.array([0, -0.3, 0], np.float32),
+                    vup=np.array([0, 1, 0], np.float32), vfov_deg=f32(42.0), aspect=f32(f32(width) / f32(height)),
+                    aperture=f32(0.0), focus_dist=f32(10.0))
     d.settings = dict(usda.DEFAULTS, strategy="power", filter="triangle", filter_radius=1.0, width=width, height=height,
                       max_depth=max_depth)
     return d

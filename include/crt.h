@@ -318,6 +318,20 @@ typedef struct CrtRayStats {
  * buffer indices j*width+i in the order the renderer traces and reports them. */
 size_t crt_shard_pixels(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, uint32_t *out);
 
+/* The tile gather of the multi-GPU path for a host that drives the collective itself (RCCL's ncclAllGather / a
+ * ncclSend-ncclRecv group over xGMI; bench.py uses torch.distributed): every rank copies its crt_film_resolve output
+ * (pixel_count x 3 floats) to the front of a zeroed buffer of crt_shard_padded_count x 3 floats — the largest shard of
+ * the frame, rounded up to 256 pixels, the same on every rank — the collective concatenates the ranks' buffers in rank
+ * order, and crt_gather_plan_assemble scatters world x padded x 3 floats into the frame (width x height x 3, buffer order
+ * j * width + i) with one launch on `stream`. The plan holds the index arrays of crt_shard_pixels in HBM.
+ * (The reference renders its tiles on Rayon workers into one shared buffer, tracer.rs:424-459.) */
+size_t crt_shard_padded_count(uint32_t width, uint32_t height, uint32_t world);
+typedef struct CrtGatherPlan CrtGatherPlan;
+CrtGatherPlan *crt_gather_plan_new(uint32_t width, uint32_t height, uint32_t world);
+void crt_gather_plan_free(CrtGatherPlan *p);
+size_t crt_gather_plan_padded_count(const CrtGatherPlan *p);
+int crt_gather_plan_assemble(const CrtGatherPlan *p, const float *d_recv, float *d_frame, void *stream);
+
 typedef struct CrtRenderer CrtRenderer; /* Renderer{camera, world, lights, settings} (tracer.rs:137-148) */
 
 /* Renderer::new: binds the committed scene (retained), one material per geom_id (rt_world.rs:111-122),

@@ -408,6 +408,23 @@ static void *worker_main(void *arg) {
   return NULL;
 }
 
+/* The whole frame on the CALLING thread, with the traversal counters of the two query kinds kept apart: the stats sink
+ * of ora_rt.c is thread-local, and World::intersect (closest hit) and World::occluded (any hit) are separate kernels on
+ * the device (k_extend / k_shadow). closest / any: zeroed by the caller, either may be NULL. */
+void ora_render_serial_trav(const OraRenderJob *job, float *rgb, OraRayStats *stats, OraTravStats *closest, OraTravStats *any) {
+  VertexRec *records = (VertexRec *)malloc(sizeof(VertexRec) * ORA_MAX_RECORDS);
+  OraRayStats total; memset(&total, 0, sizeof total);
+  ora_set_trav_stats(closest);
+  ora_set_trav_stats_any(any);
+  for (uint32_t j = 0; j < job->height; j++)
+    for (uint32_t i = 0; i < job->width; i++)
+      render_pixel(job, i, j, records, rgb + 3 * ((size_t)j * job->width + i), &total);
+  ora_set_trav_stats(NULL);
+  ora_set_trav_stats_any(NULL);
+  if (stats) *stats = total;
+  free(records);
+}
+
 void ora_render(const OraRenderJob *job, float *rgb, OraRayStats *stats, int n_threads) {
   if (n_threads < 1) n_threads = 1;
   uint32_t next = 0;

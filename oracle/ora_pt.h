@@ -40,6 +40,8 @@ typedef struct {
  * row j is the reference's Buffer row j, j = 0 at the bottom of the image, buffer.rs:45-49).
  * n_threads workers take 16x16 tiles (tracer.rs:424). */
 void ora_render(const OraRenderJob *job, float *rgb, OraRayStats *stats, int n_threads);
+/* The whole frame on the calling thread; traversal counters (bvh.rs:39-57) of closest-hit and any-hit queries apart. */
+void ora_render_serial_trav(const OraRenderJob *job, float *rgb, OraRayStats *stats, OraTravStats *closest, OraTravStats *any);
 /* The pixels idx[0..n) (linear buffer indices j*width+i): rgb[3k..3k+3) = what ora_render writes at idx[k]. */
 void ora_render_pixels(const OraRenderJob *job, const uint32_t *idx, size_t n, float *rgb, OraRayStats *stats,
                        int n_threads);

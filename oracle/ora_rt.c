@@ -382,6 +382,8 @@ struct OraScene { Bvh bvh; uint32_t n_geoms; int has_motion; };
 static __thread OraTravStats *g_stats = NULL;
 static __thread int g_depth = 0;
 void ora_set_trav_stats(OraTravStats *st) { g_stats = st; }
+static __thread OraTravStats *g_stats_any = NULL;
+void ora_set_trav_stats_any(OraTravStats *st) { g_stats_any = st; }
 #define TSTAT(field, n) do { if (g_stats) g_stats->field[g_depth > 0] += (n); } while (0)
 /* Optional per-ray phase trace for scheduling studies (profiles/simulate_scheduling.py): one char per unit of
  * traversal work in execution order — N node, P packet, s sphere, I instance entry, X instance exit. */
@@ -1216,7 +1218,12 @@ int ora_intersect(const OraScene *s, const OraRay *ray, float t_min, float t_max
 }
 int ora_occluded(const OraScene *s, const OraRay *ray, float t_min, float t_max) {
   g_depth = 0;
-  return bvh_hit_any(&s->bvh, ray, t_min, t_max);
+  if (!g_stats_any) return bvh_hit_any(&s->bvh, ray, t_min, t_max);
+  OraTravStats *keep = g_stats;  /* any-hit queries count in their own sink while one is set */
+  g_stats = g_stats_any;
+  const int occ = bvh_hit_any(&s->bvh, ray, t_min, t_max);
+  g_stats = keep;
+  return occ;
 }
 int ora_scene_bounds(const OraScene *s, float out[6]) {
   if (!s->bvh.has_bbox) return 0;

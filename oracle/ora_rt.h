@@ -73,6 +73,8 @@ int ora_linear_scan(const OraScene *s, const OraRay *ray, float t_min, float t_m
 
 /* Thread-local stats sink (NULL = off). */
 void ora_set_trav_stats(OraTravStats *st);
+/* A second thread-local sink for the any-hit queries (ora_occluded): while set, they count there instead. */
+void ora_set_trav_stats_any(OraTravStats *st);
 
 /* ---- structure introspection (for the build-parity tests) ---- */
 typedef struct {

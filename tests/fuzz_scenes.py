@@ -75,6 +75,12 @@ def build(api, recipe):
 
 
 
+def _affine12(m3, t):
+    """glam Affine3A as 12 floats: matrix3 columns x, y, z then translation (include/crt.h, crt_attach_instance)."""
+    m = np.asarray(m3, dtype=np.float32)
+    return np.concatenate([m[:, 0], m[:, 1], m[:, 2], np.asarray(t, dtype=np.float32)]).astype(np.float32)
+
+
 # ---------------------------------------------------------------- random renderable worlds (SceneDesc)
 def _rand_material(rng):
     """Every OpenPBR knob, with each optional lobe switched on at random (openpbr.rs:66-121)."""
@@ -153,6 +159,29 @@ def random_world(usda, seed, width=40, height=28):
         d.lights.insert(int(inf.integers(0, len(d.lights) + 1)), sun)
     if inf.random() < 0.33:
         d.lights.insert(int(inf.integers(0, len(d.lights) + 1)), usda.dome_light(inf.uniform(0.05, 0.8, 3)))
+    # Instances, some of them MOVING (own stream again: the worlds of seeds that draw none stay what they were): one or
+    # two prototypes — a small triangle soup, sometimes with a sphere beside it in a nested scene — placed two to five
+    # times with random scale / rotation, a third of the placements with a second transform (prim.rs:285-331). A moving
+    # placement makes the scene draw a shutter time per camera sample (tracer.rs:579-583) and carry it along the path.
+    mv = np.random.default_rng(seed ^ 0x0B1E55ED)
+    if mv.random() < 0.5:
+        for _ in range(int(mv.integers(1, 3))):
+            pv, pi = _soup(mv, int(mv.integers(6, 40)), 0.6, 0.35)
+            d.protos.append(dict(verts=pv, idx=pi))
+            proto = len(d.protos) - 1
+            if mv.random() < 0.4:  # a nested scene: the soup and a sphere, placed once each (instance depth 2)
+                d.protos.append(dict(radius=float(mv.uniform(0.15, 0.4))))
+                d.protos.append(dict(instances=[dict(proto=proto, l2w=_affine12(np.eye(3, dtype=np.float32), (0, 0, 0)), mask=0xFFFFFFFF),
+                                                dict(proto=proto + 1, l2w=_affine12(np.eye(3, dtype=np.float32), (0.0, 0.9, 0.0)), mask=0xFFFFFFFF)]))
+                proto = len(d.protos) - 1
+            mat = _rand_material(mv)
+            for _k in range(int(mv.integers(2, 6))):
+                m = (_rot(mv) * f32(mv.uniform(0.5, 1.6))).astype(np.float32)
+                t = np.array([mv.uniform(-3.5, 3.5), mv.uniform(0.6, 2.5), mv.uniform(-3.5, 3.5)], dtype=np.float32)
+                g = dict(kind="instance", proto=proto, l2w=_affine12(m, t), mask=0xFFFFFFFF, material=mat, name="inst")
+                if mv.random() < 0.34:
+                    g["l2w_end"] = _affine12(m, (t + mv.uniform(-0.8, 0.8, 3)).astype(np.float32))
+                d.geoms.append(g)
     lookfrom = np.array([rng.uniform(-2, 2), rng.uniform(1.5, 4), rng.uniform(6, 9)], dtype=np.float32)
     d.camera = dict(lookfrom=lookfrom, lookat=np.array([0, 1, 0], np.float32), vup=np.array([0, 1, 0], np.float32),
                     vfov_deg=f32(rng.uniform(30, 70)), aspect=f32(f32(width) / f32(height)),

@@ -5,7 +5,9 @@ import fixtures as fx
 
 N_RAYS = 256
 RENDERS = [("cornellbox", 48, 27, 4, 8), ("veach_mis", 48, 27, 4, 8), ("openpbr_showcase", 48, 27, 4, 12),
-           ("cornellbox_guided", 32, 32, 4, 8), ("sun_sky", 48, 27, 4, 8)]
+           ("cornellbox_guided", 32, 32, 4, 8), ("sun_sky", 48, 27, 4, 8),
+           ("motionblur", 48, 27, 4, 4), ("rectlight", 48, 27, 4, 4), ("light_visibility", 48, 27, 4, 4),
+           ("instancing", 48, 27, 4, 8)]
 
 
 def traverse_rays(name, extent):

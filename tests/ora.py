@@ -299,6 +299,7 @@ def lib():
     # integrator
     L.ora_render.argtypes = [C.POINTER(RenderJob), fp, C.POINTER(RayStats), C.c_int]
     L.ora_render_pixels.argtypes = [C.POINTER(RenderJob), C.POINTER(C.c_uint32), C.c_size_t, fp, C.POINTER(RayStats), C.c_int]
+    L.ora_render_serial_trav.argtypes = [C.POINTER(RenderJob), fp, C.POINTER(RayStats), C.POINTER(TravStats), C.POINTER(TravStats)]
     L.ora_render_pixel.restype = C.c_uint32
     L.ora_render_pixel.argtypes = [C.POINTER(RenderJob), C.c_uint32, C.c_uint32, fp, C.POINTER(RayStats)]
     L.ora_render_sample.argtypes = [C.POINTER(RenderJob), C.c_uint32, C.c_uint32, C.c_uint32, fp,

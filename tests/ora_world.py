@@ -72,6 +72,16 @@ class OracleRenderer:
         ora.lib().ora_render(C.byref(self.job), ora._fp(img), C.byref(st), threads or (os.cpu_count() or 1))
         return img, st
 
+    def render_serial_trav(self, spp, forward=1):
+        """Whole frame on the calling thread -> (image, RayStats, TravStats of the closest-hit queries, of the any-hit
+        queries): the oracle's traversal counters (bvh.rs:39-57), the two query kinds apart as on the device."""
+        self.job.forward = forward
+        self.job.spp = spp
+        img = np.zeros((self.job.height, self.job.width, 3), dtype=np.float32)
+        st, closest, anyhit = ora.RayStats(), ora.TravStats(), ora.TravStats()
+        ora.lib().ora_render_serial_trav(C.byref(self.job), ora._fp(img), C.byref(st), C.byref(closest), C.byref(anyhit))
+        return img, st, closest, anyhit
+
     def render_pixels(self, idx, spp, threads=None, forward=None):
         """The pixels idx (linear buffer indices j*width+i) only -> ([n, 3] means, RayStats over those pixels)."""
         if forward is not None:

@@ -12,8 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_the_contract_keys():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--width", "192",
-                          "--height", "108", "--spp-per-step", "4", "--cpu-spp", "1"], capture_output=True, text=True,
-                         timeout=600, cwd=ROOT)
+                          "--height", "108", "--spp-per-step", "4", "--cpu-spp", "1", "--other-configs-scale", "16"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
@@ -42,6 +42,22 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert list(rs) == ["camera_rays", "closest_hit", "shadow_rays", "vertices", "rr_tested", "rr_killed", "ended_escaped", "ended_depth"]
     assert rs["closest_hit"] == d["config"]["closest_hit"] and rs["camera_rays"] == d["config"]["camera_rays"] == 192 * 108 * 4 * 2
     assert c["host_affinity"] >= c["cores"]
+    # the same baseline on every hardware thread the process may use (what the reference's Rayon pool would take)
+    a = d["cpu_baseline_all_cores"]
+    assert a["kind"] == "port" and a["cores"] == a["host_affinity"] >= c["cores"] and a["value"] > 0
+    # the other BASELINE configurations on the same clock, after the headline: stress, MedCity at 2x its width, veach_mis,
+    # openpbr_showcase — each with its rate, its shadow rays and the tier of its dominant kernel (here at 1/16 scale)
+    oc = d["other_configs"]
+    assert [o["workload"].split()[0] for o in oc] == ["stress", "PointInstancedMedCity", "veach_mis", "openpbr_showcase"]
+    for o in oc:
+        assert "error" not in o, o
+        for k in ("workload", "value", "ms_per_step", "shadow_rays", "closest_hit", "roofline", "pipeline"):
+            assert k in o, (o["workload"], k)
+        assert o["value"] > 0 and o["ms_per_step"] > 0 and o["closest_hit"] > 0
+        for k in ("bound", "tier", "frac", "hbm_measured_frac", "l2_hit", "kernel"):
+            assert k in o["roofline"], (o["workload"], k)
+        assert o["roofline"]["bound"] in ("hbm", "latency/issue") and o["roofline"]["kernel"] in ("k_path", "k_extend", "k_shade", "k_shadow")
+    assert oc[0]["shadow_rays"] > 0 and oc[2]["shadow_rays"] > 0 and oc[3]["shadow_rays"] > 0 and oc[1]["shadow_rays"] == 0
     # rays are counted as the reference counts them (stats.rs:150-152)
     assert d["config"]["rays_total"] == d["config"]["closest_hit"] + d["config"]["shadow_rays"]
 
@@ -111,7 +127,7 @@ def test_pmc_profile_is_reported_only_for_the_build_it_was_taken_on(tmp_path, mo
     assert bench._pmc_for("veach_mis 1920x1080 64spp", "k_extend")[0] is None    # another workload: nothing to report
     assert bench._pmc_for("cornellbox 1920x1080 64spp", "k_path")[0] is None     # the other pipeline's kernel: not what was profiled
     # the committed profile, if present, is well-formed
-    real = os.path.join(ROOT, "profiles", "r03_pmc_bench.json")
+    real = bench._pmc_profile_path()  # the newest profiles/r*_pmc_bench.json
     if os.path.exists(real):
         d = json.load(open(real))
         assert len(d["kernel_source_hash"]) == 16 and d["workloads"]
@@ -120,6 +136,33 @@ def test_pmc_profile_is_reported_only_for_the_build_it_was_taken_on(tmp_path, mo
             for base, e in w["kernels"].items():
                 for k in entry:
                     assert (e[k] > 0) if k != "kernel" else e[k].startswith(base), (base, k)
+
+@pytest.mark.gpu
+def test_a_batch_that_does_not_fit_is_halved_exactly_once(crt, monkeypatch):
+    """bench.py's fallback for a part with less free HBM than the batch needs: the allocation of 8 spp fails
+    (CRT_MAX_BATCH_SLOTS makes ensure_buffers ask for more than any device has above 500 000 slots: a genuine
+    hipErrorOutOfMemory), 4 spp fit — fit_batch lands on exactly 4, not on 2: the failed allocation's error is not left
+    behind for the next batch's launch check to find. The probe leaves nothing in the film or the counters."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setenv("CRT_MAX_BATCH_SLOTS", "500000")
+    r, _ = crt.load_usda(crt.scene_path("cornellbox"), 384, 216, 8)
+    stream = torch.cuda.current_stream()
+    with pytest.raises(crt.CrtError):
+        r.render_samples(0, 8, stream)  # 663 552 paths -> 786 432 slots
+    assert bench.fit_batch(crt, r, 8, 1, stream) == 4
+    assert r.stats().camera_rays == 0 and not np.any(np.nan_to_num(r.film(), nan=1.0) != 1.0)  # 0 / 0 weight: cleared
+    r.render_samples(0, 4, stream)
+    torch.cuda.synchronize()
+    assert r.stats().camera_rays == 384 * 216 * 4
+    monkeypatch.delenv("CRT_MAX_BATCH_SLOTS")
+    ref, _ = crt.load_usda(crt.scene_path("cornellbox"), 384, 216, 8)
+    ref.render_samples(0, 4, stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(r.image().view(np.uint32), ref.image().view(np.uint32))
+
 
 def test_roofline_entry_names_the_tier_that_serves_the_bytes(monkeypatch):
     """bench.py's roofline object (CPU-only): the bound follows the MEASURED fabric traffic when PMC passes of this build

@@ -31,7 +31,12 @@ def _both(crt, name, w, h, spp, depth, batch=None):
 
 
 SCENES = [("cornellbox", 64, 64, 8, 4), ("cornellbox", 96, 54, 4, 32), ("veach_mis", 96, 54, 8, 8),
-          ("openpbr_showcase", 96, 54, 8, 12), ("cornellbox_guided", 48, 48, 8, 8), ("sun_sky", 96, 54, 8, 8)]
+          ("openpbr_showcase", 96, 54, 8, 12), ("cornellbox_guided", 48, 48, 8, 8), ("sun_sky", 96, 54, 8, 8),
+          # the reference's remaining samples: transform motion blur at RENDER level — the K_TIME draw
+          # (tracer.rs:579-583), the time plane, the cold-time kernel instances —, a RectLight, light geometry with per-light
+          # camera visibility / ray masks, a PointInstancer, nested instancers, and (outside SURVEY §8) the dome sample
+          ("motionblur", 96, 54, 8, 4), ("rectlight", 96, 54, 8, 4), ("light_visibility", 96, 54, 8, 4),
+          ("instancing", 96, 54, 8, 8), ("nested_instancing", 96, 54, 8, 8), ("domelight", 96, 54, 8, 8)]
 
 
 @pytest.mark.parametrize("name,w,h,spp,depth", SCENES)
@@ -164,7 +169,8 @@ def test_tile_shards_reassemble_the_single_gpu_image(crt):
 
 
 @pytest.mark.parametrize("scene,w,h,depth", [("openpbr_showcase", 96, 54, 12), ("cornellbox", 96, 54, 8),
-                                             ("nested_instancing", 64, 36, 6), ("stress", 96, 54, 6)])
+                                             ("nested_instancing", 64, 36, 6), ("stress", 96, 54, 6),
+                                             ("motionblur", 96, 54, 4)])
 def test_the_three_pipelines_agree(crt, tmp_path, scene, w, h, depth):
     """The renderer picks its pipeline per scene and batch (pathtrace.hip, Renderer::fused): the fused path-loop kernel on
     three workgroups per CU, or one launch per stage with the four-workgroups-per-CU traversal kernels for large batches of
@@ -183,7 +189,10 @@ def test_the_three_pipelines_agree(crt, tmp_path, scene, w, h, depth):
     outs = []
     # the four-wave kernels are built without the direct-leaf form and CRT_WIDE=1 cannot force them onto a scene that has
     # direct leaf words (packet-free: the showcase's spheres): there "stage4" is the three-wave per-stage pipeline again
-    wide = 0 if scene == "openpbr_showcase" else 1
+    # (crt_scene_engine_select says which: what CRT_WIDE=1 may be honoured on, host-only)
+    probe, _ = crt.usda.build_world(crt.usda.load(crt.scene_path(scene), w, h), crt, crt.default_material)[0], None
+    wide = 0 if probe.image_check()["direct_leaves"] else 1
+    assert wide == (0 if scene == "openpbr_showcase" else 1)
     for tag, env, want in (("fused", dict(CRT_FUSED="1"), (1, 0, 1)), ("stage3", dict(CRT_FUSED="0", CRT_WIDE="0"), (0, 0, 0)),
                            ("stage4", dict(CRT_FUSED="0", CRT_WIDE="1"), (0, wide, 0)),
                            # the batch decides: 5 spp of every pixel reach the threshold, 3 do not
@@ -220,7 +229,7 @@ def test_render_report_counts_the_scene_and_the_rays(crt, tmp_path):
     assert np.array_equal(np.ascontiguousarray(back[::-1], dtype=np.float32).view(np.uint32), img.view(np.uint32))
 
 
-def test_shade_class_partition_keeps_waves_pure_and_bits_unchanged(crt):
+def test_shade_class_partition_keeps_waves_pure_and_bits_unchanged(crt, tmp_path):
     """Shade's material-class partition (north_star: per-material sorting on wave primitives): with it the vertex step's
     waves hold one class each — lane utilisation of every class that occurs is far above the natural mix's — and the
     image and counters are the ones the unpartitioned path (CRT_PARTITION=0) produces (which the other tests of this file
@@ -237,7 +246,7 @@ def test_shade_class_partition_keeps_waves_pure_and_bits_unchanged(crt):
         "print(json.dumps(dict(stats=[st.closest_hit, st.shadow_rays, st.vertices, st.rr_killed], cls=r.shade_class_stats())))\n" % (ROOT, ROOT))
     out = {}
     for part in ("0", "1"):
-        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "crt_part%s.npy" % part)
+        path = str(tmp_path / ("crt_part%s.npy" % part))
         res = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, CRT_PARTITION=part), capture_output=True,
                              text=True, timeout=300)
         assert res.returncode == 0, res.stderr[-2000:]
@@ -264,8 +273,12 @@ def test_shade_class_partition_keeps_waves_pure_and_bits_unchanged(crt):
     ("stress", (96, 54, 6), {"CRT_LANES": "1"}, {"CRT_LANES": "3", "CRT_LANE_MIN_PATHS": "1"}),
     ("PointInstancedMedCity.usd", (96, 54, 6), {"CRT_LANES": "1"}, {"CRT_LANES": "4", "CRT_LANE_MIN_PATHS": "1"}),
     ("veach_mis.usda", (160, 90, 8), {"CRT_FUSED": "0", "CRT_LANES": "1"}, {"CRT_LANES": "3", "CRT_LANE_MIN_PATHS": "1"}),
+    # render-level motion blur (the shutter-time plane travels with the path): fused and per-stage, one lane against three
+    ("motionblur.usda", (160, 90, 4), {"CRT_LANES": "1"}, {"CRT_LANES": "3", "CRT_LANE_MIN_PATHS": "1"}),
+    ("motionblur.usda", (160, 90, 4), {"CRT_FUSED": "0", "CRT_LANES": "1"}, {"CRT_FUSED": "0", "CRT_LANES": "3", "CRT_LANE_MIN_PATHS": "1"}),
+    ("motionblur.usda", (160, 90, 4), {"CRT_FUSED": "1"}, {"CRT_FUSED": "0", "CRT_WIDE": "0"}),
 ])
-def test_round3_knobs_change_no_bit(crt, scene, res, base_env, knob):
+def test_round3_knobs_change_no_bit(crt, tmp_path, scene, res, base_env, knob):
     """Round 3's layout and scheduling choices — deduplicated material table, 16-byte camera paths, hot-first packet order,
     the deep LDS split for large trees, shade's CLASSIFY pass — change WHEN and WHERE things are read, never a result: the
     same render with the choice turned off gives the same image bits and the same eight counters."""
@@ -282,7 +295,7 @@ def test_round3_knobs_change_no_bit(crt, scene, res, base_env, knob):
         "print(json.dumps([getattr(st, f) for f, _t in st._fields_]))\n" % (ROOT, scene, scene, ROOT, scene, w, h, depth))
     out = []
     for k, extra in enumerate(({}, knob)):
-        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "crt_knob%d.npy" % k)
+        path = str(tmp_path / ("crt_knob%d.npy" % k))
         env = dict(os.environ)
         env.update(base_env)
         env.update(extra)
@@ -316,3 +329,27 @@ def test_lanes_and_single_lane_batches_alternate_within_one_renderer(crt, monkey
     assert np.array_equal(img.view(np.uint32), r1.image().view(np.uint32))
     st1 = r1.stats()
     assert (st.closest_hit, st.shadow_rays, st.vertices) == (st1.closest_hit, st1.shadow_rays, st1.vertices)
+
+
+def test_gather_plan_of_the_c_abi_assembles_what_the_indexed_stores_do(crt):
+    """crt_gather_plan_assemble (the frame assembled on the device from the ranks' padded tile buffers — what a host that
+    drives RCCL itself calls after its collective) against the per-rank indexed stores of the CPU path, for an odd frame
+    and 3 and 8 ranks; the padded count is the C ABI's on both."""
+    import torch
+    for (w, h, world) in ((100, 52, 3), (1920, 1080, 8), (33, 17, 2)):
+        n_max = crt.shard.padded_count(w, h, world)
+        dev, cpu = crt.shard.GatherPlan(w, h, world, "cuda"), crt.shard.GatherPlan(w, h, world, "cpu")
+        assert dev.n_max == cpu.n_max == n_max and n_max % 256 == 0
+        rng = np.random.default_rng(w + world)
+        recv = torch.zeros(world, n_max, 3, dtype=torch.float32)
+        for r in range(world):
+            n = crt.shard.shard_pixels(w, h, r, world).size
+            assert n <= n_max
+            recv[r, :n] = torch.from_numpy(rng.uniform(-1, 1, (n, 3)).astype(np.float32))
+        # stand-in for the collective's output: every rank's padded buffer, in rank order
+        dev.recv.copy_(recv.reshape(-1).cuda())
+        cpu.recv.copy_(recv.reshape(-1))
+        a = dev.gather(torch.zeros(0, 3, device="cuda"))  # world > 1 but dist None: assembles what recv holds
+        b = cpu.gather(torch.zeros(0, 3))
+        torch.cuda.synchronize()
+        assert np.array_equal(a.cpu().numpy().view(np.uint32), b.numpy().view(np.uint32)), (w, h, world)

@@ -27,9 +27,22 @@ def test_stress_scene_authored_settings_identical_to_oracle(crt):
     assert st.shadow_rays > 0 and st.camera_rays == 640 * 360 * 16
     bad = np.argwhere(img.view(np.uint32) != oimg.view(np.uint32))
     assert bad.shape[0] == 0, f"{bad.shape[0]} differing components, first {bad[:3]}"
-    # the traversal counters of both query kinds against the oracle's (nodes, leaves, packets, accepted hits, descents)
-    ext, sh = r.render_samples_stats(16, 4)
-    assert ext.rays > 0 and sh.rays > 0 and int(ext.instance_descents) > 0
+
+
+def test_stress_scene_traversal_counters_identical_to_oracle(crt):
+    """The traversal counters of both query kinds (bvh.rs:39-57: queries, node visits, leaves, packets, scalar primitives
+    per level; accepted hits and instance descents) of one 2-spp batch at 320x180 — k_extend's launches against the
+    oracle's closest-hit queries, k_shadow's against its any-hit queries, count for count."""
+    r, desc = crt.load_usda(crt.scene_path("stress"), 320, 180)
+    ext, sh = r.render_samples_stats(0, 2)
+    o = ora_world.OracleRenderer(desc, crt.usda)
+    _img, ost, closest, anyhit = o.render_serial_trav(2, forward=1)
+    assert int(ext.rays) == ost.closest_hit and int(sh.rays) == ost.shadow_rays and ost.shadow_rays > 0
+    for dev, ora_st, kind in ((ext, closest, "closest"), (sh, anyhit, "any")):
+        for f in ("queries", "nodes", "leaves", "packets", "prims"):
+            assert list(getattr(dev, f)) == list(getattr(ora_st, f)), (kind, f, list(getattr(dev, f)), list(getattr(ora_st, f)))
+        assert int(dev.instance_descents) == int(ora_st.instance_descents), kind
+    assert int(ext.accepted_hits) == int(closest.accepted_hits) and int(ext.instance_descents) > 0
 
 
 def test_stress_scene_bench_shape_subset(crt):
