@@ -557,24 +557,48 @@ def _pmc_for(workload_key, kernel):
     return e, "%s (git %s)" % (os.path.relpath(PMC_PROFILE, ROOT), prof.get("git_commit", "?"))
 
 
+def _cpu_quota(default):
+    """Cores' worth of CPU time this container is granted: cgroup v2 cpu.max / v1 cfs quota; a huge number if none."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+            if q != "max":
+                return max(int(round(int(q) / int(p))), 1)
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+            q, p = int(f.read()), int(g.read())
+            if q > 0:
+                return max(int(round(q / p)), 1)
+    except Exception:
+        pass
+    return 1 << 30
+
+
 def _cpu_baseline(crt, desc, args, all_cores=False):
     """The oracle (kind 'port': CPU restatement of the reference's algorithm, 16x16 tiles on worker threads as
     tracer.rs:424-459) on a bounded sample of the same workload: the full frame at --cpu-spp samples, on this box's
     16-core share — or, all_cores, on every hardware thread the process may run on (what the reference's Rayon pool
-    would take) at four times the samples."""
+    would take), capped by the container's cgroup CPU quota where one is visible."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import ora_world
     try:
         avail = len(os.sched_getaffinity(0))
     except Exception:
         avail = os.cpu_count() or 1
+    granted = _cpu_quota(avail)  # what the container may actually burn: the cgroup CPU quota, if one is set
     cores = args.cpu_threads if args.cpu_threads > 0 else min(avail, 16)  # a 1-GPU box's CPU share is 16 cores
     cpu_spp = args.cpu_spp
     if all_cores:
-        cores, cpu_spp = avail, args.cpu_spp * 4
+        # every core the box grants this process: its affinity mask (256 hardware threads on the pool's hosts) capped by
+        # the cgroup quota — 256 threads on a 16-core quota only thrash (measured: 20.8 against 31.2 Mray/s on 16)
+        cores = max(min(avail, granted), 1)
     o = ora_world.OracleRenderer(desc, crt.usda, max_depth=args.depth, forward=0)
     times = []
-    for _ in range(max(args.cpu_reps, 1)):  # min of N render-phase times (scripts/bench_scenes.sh:33 convention)
+    # min of N render-phase times (scripts/bench_scenes.sh:33 convention); the all-cores leg is one run: where the pool
+    # grants a 1-GPU box 16 cores' worth of CPU without a visible quota, 256 threads are 3 x slower per ray than 16
+    for _ in range(1 if all_cores else max(args.cpu_reps, 1)):
         t0 = time.perf_counter()
         _, st = o.render(cpu_spp, threads=cores)
         times.append(time.perf_counter() - t0)
@@ -593,6 +617,7 @@ def _cpu_baseline(crt, desc, args, all_cores=False):
         "unit": "Mray/s",
         "cores": cores,
         "host_affinity": avail,  # hardware threads this process may run on; `cores` of them were used
+        "cgroup_cpu_quota": granted if granted < 1 << 20 else None,  # cores' worth of CPU time the container is granted (null: no quota)
         "kind": "port",
         "sample": "%dx%d full frame at %d spp (%d rays), best of %d runs (%s s), reference-order estimator, host: %s" % (
             args.width, args.height, cpu_spp, st.total_rays(), len(times), " / ".join("%.1f" % t for t in times), model),

@@ -1166,7 +1166,12 @@ struct Renderer {
   // `wide`), the batch whether the per-stage form pays: its 2-3 launches per bounce cost ~0.8 ms per batch, worth it from
   // `stage_min_paths` paths up. CRT_FUSED / CRT_WIDE / CRT_STAGE_MIN_PATHS override (A/B, per-stage timing, tests).
   EngineSelect engine;     // which traversal-engine instance runs this scene's image (crt_internal.h, select_engine)
-  bool wide = false;       // = engine.wide: the scene prefers the per-stage pipeline on the four-wave kernels
+  bool wide = false;       // = engine.wide: per-stage launches run the four-wave traversal kernels
+  // The scene prefers one launch per stage for large batches: small flat triangle scenes (the four-wave kernels), and —
+  // round 4 — instance-heavy scenes and large trees on the three-wave kernels: their lanes then overlap launches of
+  // different stages and bounces, which one fused launch per lane cannot (1080p / 4K, Mray/s fused -> per-stage: stress
+  // 2460 -> 2559, PointInstancedMedCity 2191 -> 2224, the 7 M-triangle synthetic scene 3307 -> 3400; profiles/README.md).
+  bool prefer_stage = false;
   bool cam_compact_ok = true;  // CRT_CAM_COMPACT
   int shade_wide = -1;            // CRT_SHADE_WIDE: 0 = the three-wave shade kernels even beside four-wave traversal kernels (A/B)
   size_t max_batch_slots = 0;     // CRT_MAX_BATCH_SLOTS (tests): ensure_buffers fails above this many slots; 0 = no limit
@@ -1231,7 +1236,7 @@ struct Renderer {
   // the camera samples evenly (per-stage x6 7066, x10 7397, x12 8011, x20 8318).
   int batch_grid(size_t total, bool fused_pipeline) const {
     int mult = fused_pipeline ? fused_mult : stage_mult;
-    if (!mult_forced && (fused_pipeline || wide))
+    if (!mult_forced)
       while (mult < 64 && total / ((size_t)cus * mult) > ((size_t)192 << 10)) mult *= 2;
     const int g = cus * mult;
     return g > kMaxGrid ? kMaxGrid : g;
@@ -1362,7 +1367,7 @@ struct Renderer {
   // more slots than any before). Sets fused / grid for the launches that follow and p.seg_cap.
   int plan_lane(Lane &B, Params &p, uint32_t n_samples, CrtTravStats *d_tstats) {
     const size_t total = (size_t)p.n_act * n_samples;
-    fused = force_fused >= 0 ? force_fused != 0 : !(wide && total >= stage_min_paths);
+    fused = force_fused >= 0 ? force_fused != 0 : !(prefer_stage && total >= stage_min_paths);
     if (d_tstats) fused = false;  // the stats build is the per-stage one
     if (P.has_inf_lights) fused = false;  // no fused instance for lights at infinity (see k_path)
     grid = batch_grid(total, fused);
@@ -1665,6 +1670,8 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
     return nullptr;
   }
   r.wide = r.engine.wide;
+  r.prefer_stage = r.wide || P.scene.pool_stack >= (uint32_t)CRT_POOL_STACK_DEEP;
+  if (const char *e = getenv("CRT_PREFER_STAGE")) r.prefer_stage = atoi(e) != 0;  // A/B runs
   if (const char *e = getenv("CRT_CAM_COMPACT")) r.cam_compact_ok = atoi(e) != 0;
   if (const char *e = getenv("CRT_NOCLASSIFY_FROM")) r.noclassify_from = atoi(e);
   if (const char *e = getenv("CRT_TAIL_FROM")) r.tail_from = atoi(e);
@@ -1678,7 +1685,7 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
   if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) r.cus = prop.multiProcessorCount;
   r.stage_mult = r.wide ? 8 : 3;
   if (const char *e = getenv("CRT_GRID_MULT")) { if (atoi(e) > 0) { r.fused_mult = r.stage_mult = atoi(e); r.mult_forced = 1; } }  // tuning knob
-  r.fused = r.force_fused >= 0 ? r.force_fused != 0 : !r.wide;  // until the first batch: the scene's preference
+  r.fused = r.force_fused >= 0 ? r.force_fused != 0 : !r.prefer_stage;  // until the first batch: the scene's preference
   r.grid = r.batch_grid(0, r.fused);
   return R;
 }

@@ -249,6 +249,15 @@ def main():
             ("C pool 128, fetch>=32, rare>=32", sim_pool(tr, pool=128, fetch_min=32, rare_min=32)),
             ("C pool 128, fetch>=32, rare>=8", sim_pool(tr, pool=128, fetch_min=32, rare_min=8)),
             ("C pool 160, fetch>=32", sim_pool(tr, pool=160, fetch_min=32)),
+            # round 4: the wave-shared pool with >= 3 rays per lane's worth of slots and a ballot / prefix
+            # gather list per phase, at the gather's realistic price (the list, the indexed LDS reads of the state groups at
+            # 2-4-way bank conflicts, the cold state that must then live in LDS too: ~90 instructions per step instead of 50),
+            # and its limit — one pool shared by the workgroup's four waves (768 slots)
+            ("C pool 192, gather 90", sim_pool(tr, pool=192, fetch_min=32, overhead=90)),
+            ("C pool 256, gather 90", sim_pool(tr, pool=256, fetch_min=32, overhead=90)),
+            ("C pool 768 (workgroup), gather 90", sim_pool(tr, pool=768, fetch_min=32, overhead=90)),
+            ("C pool 768 (workgroup), gather 50", sim_pool(tr, pool=768, fetch_min=32, overhead=50)),
+            ("D lane-affine 2 rows, ovh 50", sim_affine(tr, rows=2, overhead=50)),
             ("D lane-affine 2 rows", sim_affine(tr, rows=2)),
             ("D lane-affine 3 rows", sim_affine(tr, rows=3)),
             ("D lane-affine 4 rows", sim_affine(tr, rows=4)),

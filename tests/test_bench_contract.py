@@ -44,7 +44,8 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert c["host_affinity"] >= c["cores"]
     # the same baseline on every hardware thread the process may use (what the reference's Rayon pool would take)
     a = d["cpu_baseline_all_cores"]
-    assert a["kind"] == "port" and a["cores"] == a["host_affinity"] >= c["cores"] and a["value"] > 0
+    quota = a["cgroup_cpu_quota"] or a["host_affinity"]
+    assert a["kind"] == "port" and a["cores"] == min(a["host_affinity"], quota) and a["value"] > 0
     # the other BASELINE configurations on the same clock, after the headline: stress, MedCity at 2x its width, veach_mis,
     # openpbr_showcase — each with its rate, its shadow rays and the tier of its dominant kernel (here at 1/16 scale)
     oc = d["other_configs"]
