@@ -104,7 +104,9 @@ def main():
     # a sample scene file, or a labelled synthetic scene ("synthetic:city[:side]", crust-render_amd/synthetic.py)
     path = crt.scene_path(args.scene)  # .usda text, .usd binary crate (PointInstancedMedCity), .usda.xz (stress)
     # N > 1: rank 0 imports the file, the other ranks receive the description in one broadcast (shard.import_once)
-    r, desc = crt.load_usda(path, args.width, args.height, args.depth, rank=rank, world=world, dist=dist)
+    setup = {}
+    hbm_free0 = torch.cuda.mem_get_info()[0]
+    r, desc = crt.load_usda(path, args.width, args.height, args.depth, rank=rank, world=world, dist=dist, timings=setup)
     spp_step = args.spp_per_step * world
     stream = torch.cuda.current_stream()
 
@@ -149,6 +151,13 @@ def main():
     st = r.stats()
     prof = r.profile_read()
     r.profile(False)
+    # what the job cost to set up and to hold, per rank (max over ranks): the import (rank 0 parses, the others wait for the
+    # broadcast), every rank's own commit, and the HBM this rank's scene image + path state + film occupy
+    setup["hbm_used_gb"] = (hbm_free0 - torch.cuda.mem_get_info()[0]) / 1e9
+    tset = torch.tensor([setup.get("import_s", 0.0), setup.get("commit_s", 0.0), setup["hbm_used_gb"]], dtype=torch.float64, device=coll)
+    if dist is not None:
+        dist.all_reduce(tset, op=dist.ReduceOp.MAX)
+    setup = dict(zip(("import_s", "commit_s", "hbm_used_gb_per_rank"), (round(float(x), 2) for x in tset.tolist())))
 
     # the job's RayStats: all eight counters (stats.rs:128-147), one all_reduce
     all_stats = crt.shard.reduce_ray_stats(st, dist, coll)
@@ -340,6 +349,7 @@ def main():
             # the second half of BASELINE's metric: wall clock to the configuration's target spp (configs[1]: 1024) at this rate
             "target_spp": 1024,
             "seconds_to_target_spp": round(elapsed * 1024.0 / (args.steps * spp_step), 4),
+            "setup": setup,
             "sharding": ("16x16 pixel tiles round-robin over ranks; one %s gather of tile buffers to rank 0" % ("RCCL" if args.backend == "nccl" else "gloo (rehearsal)")) if world > 1 else "none",
         },
         "roofline": roofline,

@@ -755,14 +755,18 @@ def scene_path(name):
     raise FileNotFoundError("no scene %r under scenes/" % name)
 
 
-def load_usda(path, width=None, height=None, max_depth=None, rank=0, world=1, variance=0.0, min_spp=None, dist=None):
+def load_usda(path, width=None, height=None, max_depth=None, rank=0, world=1, variance=0.0, min_spp=None, dist=None,
+              timings=None):
     """Scene::from_usd (scene.rs / usd_import.rs:287-424) for the text sample scenes -> (Renderer, desc).
     `path` may also name a synthetic scene: "synthetic:city" or "synthetic:city:<side>" (synthetic.py).
     variance > 0 enables adaptive stopping (the scene files' own default is 0.05; 0 = every sample, the rule for
     comparable runs, scripts/check_images.sh:5-11). dist: the job's torch.distributed module — the file is then imported
-    by rank 0 only and broadcast (shard.import_once)."""
+    by rank 0 only and broadcast (shard.import_once). timings: a dict that receives `import_s` (this rank's share of the
+    import: parsing on rank 0, waiting for the broadcast elsewhere) and `commit_s` (build_world: every rank's own commit)."""
     from . import usda, shard
     import sys
+    import time
+    t0 = time.perf_counter()
     if str(path).startswith("synthetic:"):
         from . import synthetic
         parts = str(path).split(":")
@@ -771,7 +775,11 @@ def load_usda(path, width=None, height=None, max_depth=None, rank=0, world=1, va
     else:
         desc = shard.import_once(path, width, height, dist)
     me = sys.modules[__name__]
+    t1 = time.perf_counter()
     scene, materials, protos = usda.build_world(desc, me, default_material)
+    t2 = time.perf_counter()
+    if timings is not None:
+        timings.update(import_s=t1 - t0, commit_s=t2 - t1)
     s = desc.settings
     settings = RenderSettings(s["width"], s["height"], s["max_depth"] if max_depth is None else max_depth, s["frame"],
                               s["strategy"], s["filter"], s["filter_radius"], float(variance),

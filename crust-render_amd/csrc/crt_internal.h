@@ -178,6 +178,9 @@ constexpr uint32_t kDirectIndexMask = 0x07ffffffu;
 #ifndef CRT_POOL_NODES_WIDE
 #define CRT_POOL_NODES_WIDE 26  // the four-workgroups-per-CU kernels (small flat scenes)
 #endif
+#ifndef CRT_POOL_NODES_WIDE_DEEP
+#define CRT_POOL_NODES_WIDE_DEEP 8  // ... of the four-wave kernels on a large tree (they trade the window for stack entries)
+#endif
 #ifndef CRT_DIRECT_INST
 #define CRT_DIRECT_INST 1  // 0: the direct-instance form is neither written nor understood (A/B builds)
 #endif
@@ -234,8 +237,10 @@ inline int select_engine(const DevScene &s, int want_wide, EngineSelect &e) {
   e.direct = !e.wide && CRT_DIRECT_LEAVES != 0 && has_direct_words;
   if (has_direct_words && !e.direct) return CRT_ERR_UNSUPPORTED;      // (a build without the direct form never writes one)
   const bool deep = s.pool_stack >= (uint32_t)CRT_POOL_STACK_DEEP;    // run_traversal's rule
-  e.lds_stack = e.wide ? (uint32_t)CRT_POOL_STACK_WIDE : (deep ? (uint32_t)CRT_POOL_STACK_DEEP : (uint32_t)CRT_POOL_STACK);
-  e.window = e.wide ? (uint32_t)CRT_POOL_NODES_WIDE : (deep ? (uint32_t)CRT_POOL_NODES_DEEP : (uint32_t)CRT_POOL_NODES);
+  // (the wide arena's splits: the renderer's kernels, which keep no mask plane; the batched queries have one entry less)
+  e.lds_stack = e.wide ? (uint32_t)CRT_POOL_STACK_WIDE + 1u + (deep ? 1u : 0u) : (deep ? (uint32_t)CRT_POOL_STACK_DEEP : (uint32_t)CRT_POOL_STACK);
+  e.window = e.wide ? (deep ? (uint32_t)CRT_POOL_NODES_WIDE_DEEP : (uint32_t)CRT_POOL_NODES_WIDE)
+                    : (deep ? (uint32_t)CRT_POOL_NODES_DEEP : (uint32_t)CRT_POOL_NODES);
   const int cold = (int)(s.cold & kColdAll);
   e.ext_cold = cold == 0 ? 0 : (cold == (int)kColdNormal ? (int)kColdNormal : (int)kColdAll);
   e.path_cold = cold == 0 ? 0 : (int)kColdAll;

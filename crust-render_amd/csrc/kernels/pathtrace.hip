@@ -497,7 +497,8 @@ __device__ __forceinline__ void extend_segment(const Params &P, const PathSoA &S
     }
     done++;
   };
-  run_traversal<false, STATS, WIDE, COLD>(P.scene, engine_lds, 0.001f, err, st, fetch, emit);
+  // the four-wave kernels keep no mask plane: every ray of the launch carries `mask` (UMASK, traverse_pool.hip.h)
+  run_traversal<false, STATS, WIDE, COLD, WIDE>(P.scene, engine_lds, 0.001f, err, st, fetch, emit, mask);
   if (err) atomicOr(&C->err, err);
   if (STATS) flush_stats(st, tstats, done);
 }
@@ -983,7 +984,7 @@ __device__ __forceinline__ void shadow_segment(const Params &P, const PathSoA &N
       N.c[tg] = v;
     }
   };
-  run_traversal<true, STATS, WIDE>(P.scene, engine_lds, 0.001f, err, st, fetch, emit);
+  run_traversal<true, STATS, WIDE, (int)kColdAll, WIDE>(P.scene, engine_lds, 0.001f, err, st, fetch, emit, CRT_MASK_SHADOW);
   if (err) atomicOr(&C->err, err);
   if (STATS) flush_stats(st, tstats, done);
 }

@@ -36,6 +36,15 @@ namespace dev {
 #ifndef CRT_FETCH_MIN
 #define CRT_FETCH_MIN 40
 #endif
+#ifndef CRT_NODE_SWAP
+// 1: the node loop hands a lane over to its other ray when the current one leaves the phase (round 4). Measured, Mray/s
+// off / on: cornellbox 10360 / 10258, stress 2557 / 2485, PointInstancedMedCity 2251 / 2198, the 7 M-triangle scene 3451 /
+// 3296, veach_mis 12150 / 12264: the loop runs fuller and longer, and the phases that wait for it pay more than it saves.
+#define CRT_NODE_SWAP 0
+#endif
+#ifndef CRT_STACK_RING
+#define CRT_STACK_RING 1  // the LDS part of a ray's stack holds its TOP (a ring), not its bottom (round 4)
+#endif
 #ifndef CRT_RARE_MIN
 #define CRT_RARE_MIN 24
 #endif
@@ -72,18 +81,22 @@ constexpr int kRareMin = CRT_RARE_MIN;       // run a rare phase (scalar prim / 
 constexpr int kStickyMin = CRT_STICKY_MIN;   // keep repeating node / packet steps while this many lanes stay in the phase
 
 // LDS dwords one wave needs for ROWS rays per lane.
+// UMASK: the launch's rays all carry one ray mask (the renderer's kernels: camera / indirect / shadow), so the mask plane
+// is not kept — 4 bytes per ray, one more stack entry in the same arena.
 template <int ROWS>
-constexpr int pool_lds_dwords(int stack) { return (4 + 4 + 2 + 5 + stack) * ROWS * 64; }
+constexpr int pool_lds_dwords(int stack, bool umask = false) { return (4 + 4 + 2 + (umask ? 4 : 5) + stack) * ROWS * 64; }
 
 enum : uint32_t { PH_FREE = 0, PH_NODE = 1, PH_PACKET = 2, PH_SCALAR = 3, PH_EXIT = 4, PH_EMIT = 5 };
 
-// ctl word: sp[0:8) base[8:16) level[16:19) has_packets[19] kz[20:22) swap[22]
+// ctl word: sp[0:8) base[8:16) level[16:19) has_packets[19] kz[20:22) swap[22] lo[24:32) — lo: how many of the stack's
+// bottom entries have moved out of LDS (ring form of the stack, CRT_STACK_RING)
 // aux word: found-in-level bits [0:8) (bit 0 doubles as "hit" / "occluded"), scalar entries left in the leaf [8:32)
 __device__ __forceinline__ uint32_t ctl_pack(uint32_t sp, uint32_t base, uint32_t level, uint32_t hp, uint32_t kz,
-                                             uint32_t swap, uint32_t phase) {
-  return sp | (base << 8) | (level << 16) | (hp << 19) | (kz << 20) | (swap << 22) | (phase << 23);
+                                             uint32_t swap, uint32_t lo) {
+  return sp | (base << 8) | (level << 16) | (hp << 19) | (kz << 20) | (swap << 22) | (lo << 24);
 }
-__device__ __forceinline__ uint32_t ctl_phase(uint32_t c) { return (c >> 23) & 7u; }
+// the control word with a new stack position
+__device__ __forceinline__ uint32_t ctl_sp(uint32_t c, uint32_t sp, uint32_t lo) { return (c & 0x00ffff00u) | sp | (lo << 24); }
 
 //   fetch(want, ray) -> bool : called by the whole wave; lanes with want==true may receive a ray
 //   emit(slot, hit?, Hit)    : called by a lane whose ray is finished (ANY: hit? means occluded)
@@ -109,8 +122,9 @@ __device__ __forceinline__ int wave_count(bool p) {
 // + 2 of the 28 registers of per-ray cold state a lane carries through every phase; a flat-shaded triangle scene with
 // one level of instances (cornellbox, the stress scene, PointInstancedMedCity) needs none of them, and without them the
 // four-wave kernel's 32 spilled registers are 0 (round 3: bench extend 87.8 -> 79.6 ms per step, MedCity +3.9 %).
-template <bool ANY, bool STATS, int ROWS, bool DIRECT, bool LEAN, int COLD, class Fetch, class Emit>
+template <bool ANY, bool STATS, int ROWS, bool DIRECT, bool LEAN, int COLD, bool UMASK, class Fetch, class Emit>
 __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's pool_lds_dwords<ROWS>() */, float t_min,
+                              uint32_t umask /* UMASK: the ray mask of every ray of the launch */,
                               const uint32_t *lds_nodes /* staged top of the tree */, uint32_t n_lds,
                               uint32_t n_lds_pk /* packets staged behind the n_lds nodes */, uint32_t pstack,
                               uint32_t &err, LaneStats &st, Fetch fetch, Emit emit) {
@@ -125,7 +139,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
   // space (CRT_DEFER_NORMAL) — the transform to world space (prim.rs:358-364) is then applied once, at emit,
   // instead of at every instance exit that improved the hit; kInvalid otherwise.
   enum { B_SLOT = 0, B_BU, B_BV, B_BDEFER, B_BGEOM, B_BINST };
-  uint32_t *stk = lds + 15 * RL;
+  uint32_t *stk = lds + (UMASK ? 14 : 15) * RL;
   auto at = [&](int row) { return row * 64 + lane; };
   auto W = [&](int plane, int row) -> uint32_t & { return w[plane * RL + row * 64 + lane]; };
   auto STK = [&](int e, int row) -> uint32_t & { return stk[e * RL + row * 64 + lane]; };
@@ -160,14 +174,41 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
 #pragma unroll
     for (int k = 0; k < ROWS; k++) arr[k][f] = row == k ? (decltype(arr[k][f] + 0))val : arr[k][f];
   };
-  auto push = [&](int row, uint32_t &sp, uint32_t x) {
+  // The stack: entries [lo, sp) live in LDS — the TOP of the stack, a ring of pstack slots (entry e in slot e mod
+  // pstack) — entries [0, lo) in private memory. A push onto a full ring moves the ring's OLDEST entry out; a pop that
+  // finds the ring empty takes the entry back from private memory. Pushes and pops of a ray working deep in a large tree
+  // stay in LDS; private memory is touched only on net growth past pstack and on the way back down. (Rounds 1-3 kept the
+  // BOTTOM pstack entries in LDS: every push and pop above them was a scratch access — the ten-entry split was worth
+  // +10 % to the stress scene over the six-entry one for that reason alone.) While nothing has moved out (lo == 0)
+  // slots are positions: the common case costs nothing. CRT_STACK_RING=0: the old form (A/B).
+  const uint32_t ring_inv = (65536u + pstack - 1u) / pstack;  // e / pstack == (e * ring_inv) >> 16 for e < 256, pstack <= 16
+  auto slot_of = [&](uint32_t e, uint32_t lo) -> int {
+    if (!CRT_STACK_RING || lo == 0u) return (int)e;
+    return (int)(e - ((e * ring_inv) >> 16) * pstack);
+  };
+  auto push = [&](int row, uint32_t &sp, uint32_t &lo, uint32_t x) {
+    if (CRT_STACK_RING) {
+      if (sp - lo == pstack) {  // the ring is full: its oldest entry moves out
+        if (lo >= (uint32_t)kPoolSpill) { err |= 1u; return; }
+        spill[row][lo] = STK(slot_of(lo, lo), row);
+        lo++;
+      }
+      STK(slot_of(sp, lo), row) = x;
+      sp++;
+      return;
+    }
     if (sp < pstack) STK((int)sp, row) = x;
     else if (sp - pstack < (uint32_t)kPoolSpill) spill[row][sp - pstack] = x;
     else { err |= 1u; return; }
     sp++;
   };
-  auto pop = [&](int row, uint32_t &sp) -> uint32_t {
+  auto pop = [&](int row, uint32_t &sp, uint32_t &lo) -> uint32_t {
     sp--;
+    if (CRT_STACK_RING) {
+      if (sp >= lo) return STK(slot_of(sp, lo), row);
+      lo--;  // the ring is empty: sp == lo - 1, the entry is the last one that moved out
+      return spill[row][sp];
+    }
     return sp < pstack ? STK((int)sp, row) : spill[row][sp - pstack];
   };
   // What the ray does next: the rest of the leaf's scalar list, else the next stack entry, else leave the tree.
@@ -187,12 +228,12 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
     cursor = 0;  // packet counter while in PH_PACKET
     return PH_PACKET;
   };
-  auto advance = [&](int row, uint32_t &sp, uint32_t base, uint32_t level, uint32_t &rem, uint32_t &cur,
+  auto advance = [&](int row, uint32_t &sp, uint32_t &lo, uint32_t base, uint32_t level, uint32_t &rem, uint32_t &cur,
                      uint32_t &cursor) -> uint32_t {
     if (rem > 0) return PH_SCALAR;
     for (;;) {
       if (sp == base) return level > 0 ? PH_EXIT : PH_EMIT;
-      const uint32_t e = pop(row, sp);
+      const uint32_t e = pop(row, sp, lo);
       if (e & kLeafTag) {
         if (e == kInvalid) continue;
         return leaf_word(e, level, cur, cursor, rem);
@@ -228,7 +269,8 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
     const bool empty = S.root == kInvalid;  // bvh.rs:442-444
     W(W_CTL, row) = ctl_pack(0, 0, 0, S.has_packets ? 1u : 0u, kz, swap, 0);
     W(W_CUR, row) = S.root;
-    W(W_AUX, row) = 0; W(W_CURSOR, row) = 0; W(W_MASK, row) = in.mask; wr(best, row, B_SLOT, in.slot);
+    W(W_AUX, row) = 0; W(W_CURSOR, row) = 0; wr(best, row, B_SLOT, in.slot);
+    if (!UMASK) W(W_MASK, row) = in.mask;
     wr(best, row, B_BU, 0); wr(best, row, B_BV, 0); wr(best, row, B_BDEFER, kInvalid); wr(best, row, B_BGEOM, kInvalid);
     wr(best, row, B_BINST, kInvalid);
     wr(side_d, row, 0, in.dx); wr(side_d, row, 1, in.dy); wr(side_d, row, 2, in.dz); wr(side_d, row, 3, in.time);
@@ -299,7 +341,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
         else break;  // every slot is free (and the source is dry, or the fetch above would have run)
       }
     }
-    const bool mine = (have & (1u << q)) != 0;
+    bool mine = (have & (1u << q)) != 0;
     int row = 0;
 #pragma unroll
     for (int k = ROWS - 1; k >= 0; k--)
@@ -312,12 +354,22 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
       // ================= node expansion (bvh.rs:455-505), repeated while most of the lanes stay in it =================
       // Every lane loads (its own slot of `row`: always addressable); lanes without a ray in this phase just
       // carry the values along, `act` keeps them out of every effect. No zero-initialisation, no masked loads.
-      const float4 g0 = f0[at(row)], g1 = f1[at(row)];
-      const uint32_t c = W(W_CTL, row);
+      float4 g0 = f0[at(row)], g1 = f1[at(row)];
+      uint32_t c = W(W_CTL, row);
       uint32_t cur = W(W_CUR, row), cursor = 0, rem = 0;
-      uint32_t sp = c & 0xffu;
-      const uint32_t base = (c >> 8) & 0xffu, level = (c >> 16) & 7u;
+      uint32_t sp = c & 0xffu, lo = c >> 24;
+      uint32_t base = (c >> 8) & 0xffu, level = (c >> 16) & 7u;
       bool act = mine;
+      // the ray of slot `row` leaves the loop: its control words go back to LDS
+      auto retire = [&]() {
+        W(W_CTL, row) = ctl_sp(c, sp, lo);
+        W(W_CUR, row) = cur;
+        if (next == PH_PACKET) W(W_CURSOR, row) = 0;
+        if (next == PH_SCALAR) {  // a direct leaf: the scalar list starts at once
+          W(W_CURSOR, row) = cursor;
+          W(W_AUX, row) = (W(W_AUX, row) & 0xffu) | (rem << 8);
+        }
+      };
       for (;;) {
         if (act) {
           CRT_PHASE(2)
@@ -401,10 +453,10 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
             n_tot = on[0] + on[1] + on[2] + on[3];
           }
           if (n_tot == 0) {
-            next = advance(row, sp, base, level, rem, cur, cursor);
+            next = advance(row, sp, lo, base, level, rem, cur, cursor);
           } else {
             uint32_t top_e = 0;
-            if (sp + n_tot - 1 <= pstack) {  // the stored entries fit the LDS part of the stack
+            if (lo == 0u && sp + n_tot - 1 <= pstack) {  // the stored entries fit the LDS part of the stack, nothing has moved out
 #pragma unroll
               for (int i = 0; i < 4; i++) {
                 if (on[i]) {
@@ -420,11 +472,11 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
                 for (int i = 0; i < 4; i++)
                   if (on[i] && pos[i] == k) e = ent[i];
                 if (k == n_tot - 1) top_e = e;
-                else push(row, sp, e);
+                else push(row, sp, lo, e);
               }
             }
             if (top_e & kLeafTag) {
-              if (top_e == kInvalid) next = advance(row, sp, base, level, rem, cur, cursor);
+              if (top_e == kInvalid) next = advance(row, sp, lo, base, level, rem, cur, cursor);
               else next = leaf_word(top_e, level, cur, cursor, rem);
             } else {
               cur = top_e;
@@ -433,24 +485,40 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
           }
           act = next == PH_NODE;
         }
+        // SWAP: a lane whose ray has just left the node phase hands the lane over to its OTHER ray if that one waits
+        // for a node step — inside the loop, for the price of four LDS stores and four loads, instead of idling until
+        // the loop ends and a whole scheduling round re-picks the rows. The loop stays fuller and runs longer; a ray's
+        // own sequence of steps is untouched (results and counters unchanged).
+        if (CRT_NODE_SWAP && ROWS == 2) {
+          if (mine && !act) {
+            retire();
+#pragma unroll
+            for (int k = 0; k < ROWS; k++)
+              if (k == row) ph[k] = next;
+            const uint32_t ph_other = row == 0 ? ph[ROWS - 1] : ph[0];
+            if (ph_other == PH_NODE) {
+              row ^= 1;
+              g0 = f0[at(row)]; g1 = f1[at(row)];
+              c = W(W_CTL, row);
+              cur = W(W_CUR, row); cursor = 0; rem = 0;
+              sp = c & 0xffu; lo = c >> 24; base = (c >> 8) & 0xffu; level = (c >> 16) & 7u;
+              next = PH_NODE;
+              act = true;
+            } else {
+              mine = false;  // nothing of this lane is in flight in this loop any more
+            }
+          }
+        }
         if (wave_count(act) < kStickyMin) break;  // wave-uniform
       }
-      if (mine) {
-        W(W_CTL, row) = (c & ~0xffu) | sp;
-        W(W_CUR, row) = cur;
-        if (next == PH_PACKET) W(W_CURSOR, row) = 0;
-        if (next == PH_SCALAR) {  // a direct leaf: the scalar list starts at once
-          W(W_CURSOR, row) = cursor;
-          W(W_AUX, row) = (W(W_AUX, row) & 0xffu) | (rem << 8);
-        }
-      }
+      if (mine) retire();
     } else if (q == PH_PACKET) {
       // ============ Tri4 packets of the current leaf (bvh.rs:514-562, triangle.rs:276-348), one per turn ============
       const float4 g0 = f0[at(row)], g1 = f1[at(row)];  // unconditional, as in the node phase
       const float2 g2 = f2[at(row)];
-      const uint32_t c = W(W_CTL, row), rmask = W(W_MASK, row);
+      const uint32_t c = W(W_CTL, row), rmask = UMASK ? umask : W(W_MASK, row);
       uint32_t cur = W(W_CUR, row), k = W(W_CURSOR, row), aux = W(W_AUX, row);
-      uint32_t sp = c & 0xffu;
+      uint32_t sp = c & 0xffu, lo = c >> 24;
       const uint32_t base = (c >> 8) & 0xffu, level = (c >> 16) & 7u;
       int kx, ky, kz;
       unpack_k(c, kx, ky, kz);
@@ -640,10 +708,10 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
         if (next == PH_PACKET) {
           cursor = k;
         } else if (next == PH_SCALAR) {  // the leaf's packets are done: scalar list, or on to the next entry
-          next = advance(row, sp, base, level, rem, cur, cursor);
+          next = advance(row, sp, lo, base, level, rem, cur, cursor);
           aux = (aux & 0xffu) | (rem << 8);
         }
-        W(W_CTL, row) = (c & ~0xffu) | sp;
+        W(W_CTL, row) = ctl_sp(c, sp, lo);
         W(W_CUR, row) = cur;
         W(W_CURSOR, row) = cursor;
         W(W_AUX, row) = aux;
@@ -654,13 +722,13 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
         CRT_PHASE(4)
         const float4 g0 = f0[at(row)];
         uint32_t c = W(W_CTL, row);
-        uint32_t sp = c & 0xffu;
+        uint32_t sp = c & 0xffu, lo = c >> 24;
         uint32_t base = (c >> 8) & 0xffu, level = (c >> 16) & 7u;
         const uint32_t hp = (c >> 19) & 1u;
         uint32_t cur = W(W_CUR, row);
         uint32_t cursor = W(W_CURSOR, row);
         uint32_t aux = W(W_AUX, row);
-        const uint32_t rmask = W(W_MASK, row);
+        const uint32_t rmask = UMASK ? umask : W(W_MASK, row);
         uint32_t rem = aux >> 8;  // 24 bits: a leaf's scalar list is not limited to 255 entries (make_leaf fallbacks)
         float closest = g0.w;
         const float dx = rd(side_d, row, 0), dy = rd(side_d, row, 1), dz = rd(side_d, row, 2), time = rd(side_d, row, 3);
@@ -747,7 +815,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
                 uint32_t kz, swap;
                 store_ray(row, r, (ih.y & 1u) != 0, closest, kz, swap);
                 c = ctl_pack(sp, base, level, ih.y & 1u, kz, swap, 0);
-                push(row, sp, ih.x);
+                push(row, sp, lo, ih.x);
               }
             }
           }
@@ -813,9 +881,9 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
         }
         }
         if (occluded) { aux |= 1u; next = PH_EMIT; }
-        else next = advance(row, sp, base, level, rem, cur, cursor);
+        else next = advance(row, sp, lo, base, level, rem, cur, cursor);
         aux = (aux & 0xffu) | (rem << 8);
-        W(W_CTL, row) = (c & ~0xffffu) | sp | (base << 8);
+        W(W_CTL, row) = (c & 0x00ff0000u) | sp | (base << 8) | (lo << 24);
         W(W_CUR, row) = cur;
         W(W_CURSOR, row) = cursor;
         W(W_AUX, row) = aux;
@@ -825,7 +893,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
       if (mine) {
         CRT_PHASE(5)
         const uint32_t c = W(W_CTL, row);
-        uint32_t sp = c & 0xffu;
+        uint32_t sp = c & 0xffu, lo = c >> 24;
         uint32_t level = (c >> 16) & 7u;
         uint32_t aux = W(W_AUX, row);
         uint32_t cur = W(W_CUR, row);
@@ -868,8 +936,8 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
         store_ray(row, r, f.has_packets != 0, closest, kz, swap);
         uint32_t cursor = f.cursor;
         uint32_t rem = f.cend;
-        next = advance(row, sp, f.base, level, rem, cur, cursor);
-        W(W_CTL, row) = ctl_pack(sp, f.base, level, f.has_packets ? 1u : 0u, kz, swap, 0);
+        next = advance(row, sp, lo, f.base, level, rem, cur, cursor);
+        W(W_CTL, row) = ctl_pack(sp, f.base, level, f.has_packets ? 1u : 0u, kz, swap, lo);
         W(W_CUR, row) = cur;
         W(W_CURSOR, row) = cursor;
         W(W_AUX, row) = (aux & 0xffu) | (rem << 8);
@@ -944,19 +1012,35 @@ constexpr int kEngineLdsDwords = kEngineLdsFlat > kEngineLdsDeep ? kEngineLdsFla
 // (crt_internal.h, wide_split).
 constexpr int kPoolStackWide = CRT_POOL_STACK_WIDE;
 constexpr int kPoolNodesWide = CRT_POOL_NODES_WIDE;  // crt_internal.h
-constexpr int kEngineLdsWide = (kBlock / 64) * pool_lds_dwords<CRT_POOL_ROWS>(kPoolStackWide) + kPoolNodesWide * kLdsNodeStride;
+// Round 4: the wide arena's split follows the tree too. A large tree (DevScene::pool_stack = the deep split's, scene.cpp)
+// trades the node window — 26 of its 100 000 nodes — for stack entries: 4 + 8 instead of 3 + 26; and the renderer's
+// kernels, whose rays all carry one mask (UMASK: no mask plane), have one more entry in the same bytes: 4 + 26 for small
+// trees, 5 + 8 for large ones. (Four-wave kernels at 3 + 26 against three-wave ones at 10 + 16, Mray/s: stress 2521 /
+// 2466, the 7 M-triangle scene 3172 / 3307; at 6 + 72 on three waves: stress 2249 — the depth of the LDS part of the
+// stack is what large trees pay for, profiles/README.md.)
+#ifndef CRT_POOL_NODES_WIDE_DEEP
+#define CRT_POOL_NODES_WIDE_DEEP 8
+#endif
+__host__ __device__ constexpr int wide_stack(bool deep_tree, bool umask) { return kPoolStackWide + (deep_tree ? 1 : 0) + (umask ? 1 : 0); }
+__host__ __device__ constexpr int wide_nodes(bool deep_tree) { return deep_tree ? CRT_POOL_NODES_WIDE_DEEP : kPoolNodesWide; }
+constexpr int wide_arena(bool deep_tree, bool umask) {
+  return (kBlock / 64) * pool_lds_dwords<CRT_POOL_ROWS>(wide_stack(deep_tree, umask), umask) + wide_nodes(deep_tree) * kLdsNodeStride;
+}
+constexpr int imax(int a, int b) { return a > b ? a : b; }
+constexpr int kEngineLdsWide = imax(imax(wide_arena(false, false), wide_arena(false, true)), imax(wide_arena(true, false), wide_arena(true, true)));
 static_assert(kEngineLdsWide * 4 + 512 <= 40 * 1024, "four workgroups of the wide split per CU");
 // Runs the traversal for one workgroup. `lds` = kEngineLdsDwords dwords (WIDE: kEngineLdsWide), 16-byte aligned.
 // Contains a workgroup barrier: call from uniform control flow, after the shared variables the callbacks use are
 // initialised.
-template <bool ANY, bool STATS, bool WIDE, int COLD = (int)kColdAll, class Fetch, class Emit>
+template <bool ANY, bool STATS, bool WIDE, int COLD = (int)kColdAll, bool UMASK = false, class Fetch, class Emit>
 __device__ __forceinline__ void run_traversal(const DevScene &S, uint32_t *lds, float t_min, uint32_t &err, LaneStats &st,
-                                              Fetch fetch, Emit emit) {
+                                              Fetch fetch, Emit emit, uint32_t umask = 0u) {
   // the split of the arena is the scene's (uniform): clamp to what the arena was sized for
-  const uint32_t pstack = WIDE ? (uint32_t)kPoolStackWide
-                               : (S.pool_stack >= (uint32_t)kPoolStackDeep ? (uint32_t)kPoolStackDeep : (uint32_t)kPoolStack);
-  const int pnodes = WIDE ? kPoolNodesWide : (pstack == (uint32_t)kPoolStackDeep ? kPoolNodesDeep : kPoolNodes);
-  const int wave_dwords = pool_lds_dwords<CRT_POOL_ROWS>((int)pstack);
+  const bool deep_tree = S.pool_stack >= (uint32_t)kPoolStackDeep;
+  const uint32_t pstack = WIDE ? (uint32_t)wide_stack(deep_tree, UMASK)
+                               : (deep_tree ? (uint32_t)kPoolStackDeep : (uint32_t)kPoolStack);
+  const int pnodes = WIDE ? wide_nodes(deep_tree) : (deep_tree ? kPoolNodesDeep : kPoolNodes);
+  const int wave_dwords = pool_lds_dwords<CRT_POOL_ROWS>((int)pstack, UMASK);
   uint32_t *lds_nodes = lds + (kBlock / 64) * wave_dwords;
   uint32_t n_lds_pk;
   const uint32_t n_lds = stage_nodes(S, lds_nodes, pnodes, n_lds_pk);  // ends with a barrier
@@ -969,11 +1053,11 @@ __device__ __forceinline__ void run_traversal(const DevScene &S, uint32_t *lds, 
   // kernels are instantiated per DevScene::cold and chosen on the host — several engine copies inside one kernel cost
   // the register allocator more than the leaner copy saves (the fused kernel went from 11 to 89 spilled registers).
   // Any-hit traversal keeps none of that state by construction; the batched queries report u and v and take kColdAll.
-  // The four-wave kernels never meet a direct-leaf scene (wide_split, crt_internal.h).
+  // The four-wave kernels never meet a direct-leaf scene (crt_internal.h, select_engine).
 #ifndef CRT_WIDE_LEAN
 #define CRT_WIDE_LEAN 1  // the four-wave kernels fetch a packet in stages (LEAN); 0: whole, as the three-wave ones (A/B)
 #endif
-#define CRT_ENGINE(D) traverse_pool<ANY, STATS, CRT_POOL_ROWS, D, (WIDE && CRT_WIDE_LEAN != 0), COLD>(S, wave_lds, t_min, lds_nodes, n_lds, n_lds_pk, pstack, err, st, fetch, emit)
+#define CRT_ENGINE(D) traverse_pool<ANY, STATS, CRT_POOL_ROWS, D, (WIDE && CRT_WIDE_LEAN != 0), COLD, UMASK>(S, wave_lds, t_min, umask, lds_nodes, n_lds, n_lds_pk, pstack, err, st, fetch, emit)
   if (CRT_DIRECT_LEAVES != 0 && !WIDE && S.direct_leaves != 0) CRT_ENGINE(true);
   else CRT_ENGINE(false);
 #undef CRT_ENGINE

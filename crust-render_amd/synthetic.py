@@ -124,7 +124,7 @@ def big(width=640, height=360, side=512, max_depth=6):
     """SYNTHETIC (generated in code, not a reference file; labelled so wherever it is reported). The out-of-cache
     path-traced workload: the reference's `tri_spheres` probe layout (ray_throughput.rs:50-65: 27 UV spheres on a 3x3x3
     grid at 2.5 spacing) at `side` x `side`/2 quads per sphere — 512 -> 7 077 888 triangles, a 1.03 GB device image, four
-    times the Infinity Cache — on a floor under a 10 x 10 RectLight, seen from outside the cluster. Diffuse and rough-metal
+    times the Infinity Cache — in a closed room under a 10 x 10 RectLight on its ceiling, the cluster filling the frame. Diffuse and rough-metal
     looks only (simple material table, flat shading: the leanest kernel instances), depth 6: camera rays, incoherent bounce
     rays between the spheres and one shadow ray per vertex all traverse a tree that does not fit any cache — the
     north_star's ">= 40 % of HBM peak in the traversal kernel" is physically reachable only on a scene like this
@@ -145,10 +145,15 @@ def big(width=640, height=360, side=512, max_depth=6):
                 d.geoms.append(dict(kind="mesh", verts=v, idx=i, mask=0xFFFFFFFF, material=dict(looks[k % len(looks)]),
                                     name="ball_%d" % k))
                 k += 1
-    g = np.array([(-14, -3.9, -14), (14, -3.9, -14), (14, -3.9, 14), (-14, -3.9, 14)], dtype=np.float32)
-    d.geoms.append(dict(kind="mesh", verts=g, idx=np.array([(0, 2, 1), (0, 3, 2)], np.uint32), mask=0xFFFFFFFF,
-                        material={"base_color": (0.6, 0.6, 0.58), "specular_weight": 0.0}, name="floor"))
-    o = np.array([-5.0, 7.5, -5.0], dtype=np.float32)
+    # a closed room around the cluster (floor, four walls, ceiling: 12 triangles, normals facing in): paths keep bouncing
+    # to the depth limit instead of leaving for the sky, so most of a batch's rays are incoherent bounce and shadow rays
+    lo, hi = np.array([-9.0, -3.9, -9.0]), np.array([9.0, 9.0, 13.0])
+    c = np.array([[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])], dtype=np.float32)
+    quads = [(0, 1, 5, 4), (2, 6, 7, 3), (0, 2, 3, 1), (4, 5, 7, 6), (0, 4, 6, 2), (1, 3, 7, 5)]  # floor, ceiling, -x, +x, -z, +z
+    room = np.array([t for q in quads for t in ((q[0], q[1], q[2]), (q[0], q[2], q[3]))], dtype=np.uint32)
+    d.geoms.append(dict(kind="mesh", verts=c, idx=room, mask=0xFFFFFFFF,
+                        material={"base_color": (0.62, 0.62, 0.60), "specular_weight": 0.0}, name="room"))
+    o = np.array([-5.0, 8.9, -5.0], dtype=np.float32)
     eu, ev = np.array([10.0, 0.0, 0.0], dtype=np.float32), np.array([0.0, 0.0, 10.0], dtype=np.float32)
     rad = (9.0, 8.6, 8.0)
     gid = len(d.geoms)
@@ -157,8 +162,8 @@ def big(width=640, height=360, side=512, max_depth=6):
                         material={"_preset": "emissive", "emission_color": rad}, name="light"))
     d.lights.append(dict(kind="rect", geom_id=gid, radiance=np.array(rad, np.float32), origin=o, edge_u=eu, edge_v=ev,
                          normal=np.array([0, -1, 0], np.float32)))
-    d.camera = dict(lookfrom=np.array([6.5, 3.5, 11.0], np.float32), lookat=np.array([0, -0.3, 0], np.float32),
-                    vup=np.array([0, 1, 0], np.float32), vfov_deg=f32(42.0), aspect=f32(f32(width) / f32(height)),
+    d.camera = dict(lookfrom=np.array([5.5, 3.0, 10.0], np.float32), lookat=np.array([0, -0.2, 0], np.float32),
+                    vup=np.array([0, 1, 0], np.float32), vfov_deg=f32(38.0), aspect=f32(f32(width) / f32(height)),
                     aperture=f32(0.0), focus_dist=f32(10.0))
     d.settings = dict(usda.DEFAULTS, strategy="power", filter="triangle", filter_radius=1.0, width=width, height=height,
                       max_depth=max_depth)

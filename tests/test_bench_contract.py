@@ -59,6 +59,8 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
             assert k in o["roofline"], (o["workload"], k)
         assert o["roofline"]["bound"] in ("hbm", "latency/issue") and o["roofline"]["kernel"] in ("k_path", "k_extend", "k_shade", "k_shadow")
     assert oc[0]["shadow_rays"] > 0 and oc[2]["shadow_rays"] > 0 and oc[3]["shadow_rays"] > 0 and oc[1]["shadow_rays"] == 0
+    # what the job cost to set up and to hold (import once, per-rank commit, per-rank HBM)
+    assert set(d["config"]["setup"]) == {"import_s", "commit_s", "hbm_used_gb_per_rank"} and d["config"]["setup"]["hbm_used_gb_per_rank"] > 0
     # rays are counted as the reference counts them (stats.rs:150-152)
     assert d["config"]["rays_total"] == d["config"]["closest_hit"] + d["config"]["shadow_rays"]
 

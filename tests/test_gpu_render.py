@@ -353,3 +353,24 @@ def test_gather_plan_of_the_c_abi_assembles_what_the_indexed_stores_do(crt):
         b = cpu.gather(torch.zeros(0, 3))
         torch.cuda.synchronize()
         assert np.array_equal(a.cpu().numpy().view(np.uint32), b.numpy().view(np.uint32)), (w, h, world)
+
+
+@pytest.mark.parametrize("env", [{}, {"CRT_FUSED": "0", "CRT_WIDE": "1"}, {"CRT_FUSED": "1"}])
+def test_synthetic_big_identical_to_oracle(crt, env, monkeypatch):
+    """The labelled synthetic out-of-cache workload (synthetic.big: 27 tessellated spheres in a closed room under a rect
+    light; here 96 x 48 quads per sphere = 248 832 triangles, the bench runs 512 x 256 = 7.08 M): a large tree — the deep
+    LDS split — through the default pipeline, through the four-wave kernels on their large-tree split (five stack entries,
+    eight-node window, no mask plane) and through the fused kernel: image and all eight counters identical to the oracle."""
+    import torch
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    r, desc = crt.load_usda("synthetic:big:96", 96, 54, 6)
+    sel = r.scene.engine_select(-2)
+    assert sel["wide"] == (1 if env.get("CRT_WIDE") == "1" else 0) and sel["lds_stack"] == (5 if sel["wide"] else 10)
+    r.render_samples(0, 4)
+    torch.cuda.synchronize()
+    img, st = r.image(), r.stats()
+    oimg, ost = ora_world.OracleRenderer(desc, crt.usda, max_depth=6).render(4, forward=1)
+    for f, _t in ora.RayStats._fields_:
+        assert getattr(st, f) == getattr(ost, f), (env, f)
+    assert st.shadow_rays > 0 and st.ended_depth > 0 and np.array_equal(img.view(np.uint32), oimg.view(np.uint32))
