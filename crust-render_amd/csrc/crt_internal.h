@@ -201,8 +201,14 @@ constexpr uint32_t kDirectIndexMask = 0x07ffffffu;
 // lose 7 %, an instanced city 6 %, sphere-only scenes are indifferent.
 // ... and only images WITHOUT direct child words: the four-wave kernels are built without the direct-leaf engine copy
 // (run_traversal), so a direct word would be read as a leaf index (the round-3 fault, profiles/README.md).
-inline bool wide_split(const DevScene &s) {
-  return s.direct_leaves == 0 && s.pool_stack < 10u && s.n_packets > 0 && s.n_nodes <= 1024u;
+// Round 4: LARGE flat trees too, in the renderer — its four-wave kernels keep no mask plane and split their arena by tree
+// (five stack entries + an eight-node window; traverse_pool.hip.h): the reference's stress scene 2538 -> 2738 Mray/s
+// (+7.9 %), the 7 M-triangle synthetic scene +0.7 %. The batched queries (one stack entry less: per-ray masks) keep the
+// three-wave kernels on those trees, as do the mid-size ones (1 024 < nodes <= 2 048: the flat 6 + 72 split).
+inline bool wide_split(const DevScene &s, bool renderer = false) {
+  if (s.direct_leaves != 0 || s.n_packets == 0) return false;
+  if (s.pool_stack >= 10u) return renderer && s.n_nodes > 2048u;  // the deep split chosen for a large tree, not for instances
+  return s.n_nodes <= 1024u;
 }
 
 // LDS stack entries per ray of the three engine splits (kernels/traverse_pool.hip.h sizes its arenas from these).
@@ -228,12 +234,13 @@ struct EngineSelect {
   int ext_cold = (int)kColdAll;         // k_extend<., ., COLD>: none / the pending normal only / everything
   int path_cold = (int)kColdAll;        // k_path<., ., COLD> of simple scenes: none / everything
 };
-// want_wide: -1 = the scene's own preference (wide_split), 0 / 1 = asked for (CRT_WIDE, tests). CRT_OK, or
+// want_wide: -1 = the scene's own preference (wide_split), 0 / 1 = asked for (CRT_WIDE, tests); renderer: the choice for
+// the renderer's kernels (the batched queries' differs on large trees, wide_split). CRT_OK, or
 // CRT_ERR_UNSUPPORTED when what was asked for cannot decode the image — nothing is launched then.
-inline int select_engine(const DevScene &s, int want_wide, EngineSelect &e) {
+inline int select_engine(const DevScene &s, int want_wide, EngineSelect &e, bool renderer = false) {
   const bool has_direct_words = s.direct_leaves != 0;
   if (want_wide > 0 && has_direct_words) return CRT_ERR_UNSUPPORTED;  // WIDE kernels carry no direct-leaf engine
-  e.wide = want_wide < 0 ? wide_split(s) : want_wide != 0;
+  e.wide = want_wide < 0 ? wide_split(s, renderer) : want_wide != 0;
   e.direct = !e.wide && CRT_DIRECT_LEAVES != 0 && has_direct_words;
   if (has_direct_words && !e.direct) return CRT_ERR_UNSUPPORTED;      // (a build without the direct form never writes one)
   const bool deep = s.pool_stack >= (uint32_t)CRT_POOL_STACK_DEEP;    // run_traversal's rule
@@ -255,9 +262,9 @@ inline bool engine_accepts(const EngineSelect &e, const DevScene &s, int kernel_
 // CRT_WIDE (A/B runs, tests): 1 asks for the four-wave kernels, 0 for the three-wave ones. A request the image cannot
 // take falls back to the scene's own preference — the knob sweeps whole test sets, direct-leaf scenes included.
 int wide_request();  // -1 unset
-inline int select_engine_env(const DevScene &s, EngineSelect &e) {
-  if (select_engine(s, wide_request(), e) == CRT_OK) return CRT_OK;
-  return select_engine(s, -1, e);
+inline int select_engine_env(const DevScene &s, EngineSelect &e, bool renderer = false) {
+  if (select_engine(s, wide_request(), e, renderer) == CRT_OK) return CRT_OK;
+  return select_engine(s, -1, e, renderer);
 }
 
 struct DeviceImage {

@@ -1665,7 +1665,7 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
   // trip (profiles/README.md).
   // select_engine decides, from the image, which engine instance runs it; CRT_WIDE=0/1 (A/B, tests) is a request it
   // honours only where the image can be decoded by what was asked for (never the four-wave kernels on direct words)
-  if (select_engine_env(P.scene, r.engine) != CRT_OK) {
+  if (select_engine_env(P.scene, r.engine, true) != CRT_OK) {
     set_error_text("crt_renderer_new: no traversal-engine instance of this build can decode the scene image");
     delete R;
     return nullptr;

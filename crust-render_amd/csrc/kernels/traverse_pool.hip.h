@@ -43,7 +43,14 @@ namespace dev {
 #define CRT_NODE_SWAP 0
 #endif
 #ifndef CRT_STACK_RING
-#define CRT_STACK_RING 1  // the LDS part of a ray's stack holds its TOP (a ring), not its bottom (round 4)
+// 1: the LDS part of a ray's stack holds its TOP (a ring of pstack slots), not its bottom (round 4). Measured, Mray/s
+// off / on: cornellbox 10273 / 10169, stress 2498 / 2438 (four-wave 2648 / 2546; six-entry split 2249 / 2111),
+// PointInstancedMedCity 2224 / 2182, the 7 M-triangle scene 3384 / 3334: what a shallow LDS part costs is not the
+// latency of its private-memory entries but the instructions of the path that handles them (CRT_SPILL_UNROLLED).
+#define CRT_STACK_RING 0
+#endif
+#ifndef CRT_SPILL_UNROLLED
+#define CRT_SPILL_UNROLLED 1  // a node step below the LDS part of the stack stores its entries with predicated writes, not in a loop
 #endif
 #ifndef CRT_RARE_MIN
 #define CRT_RARE_MIN 24
@@ -465,7 +472,24 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
                 }
               }
               sp += n_tot - 1;
-            } else {  // deep stack: one entry at a time through the spill path
+            } else if (!CRT_STACK_RING && CRT_SPILL_UNROLLED) {
+              // deep stack: the same independent predicated writes, each to LDS or to the private part by its position
+              // (rounds 1-3 ran a loop over the entries here — a select chain and a branchy push per entry, for every node
+              // step of a ray working below the LDS part of its stack)
+#pragma unroll
+              for (int i = 0; i < 4; i++) {
+                if (on[i]) {
+                  if (pos[i] == n_tot - 1) top_e = ent[i];
+                  else {
+                    const uint32_t at = sp + pos[i];
+                    if (at < pstack) STK((int)at, row) = ent[i];
+                    else if (at - pstack < (uint32_t)kPoolSpill) spill[row][at - pstack] = ent[i];
+                    else err |= 1u;
+                  }
+                }
+              }
+              sp += n_tot - 1;
+            } else {  // one entry at a time through push()
               for (uint32_t k = 0; k < n_tot; k++) {
                 uint32_t e = 0;
 #pragma unroll

@@ -601,7 +601,9 @@ int scene_engine_select(const Scene &scene, int want_wide, uint32_t out[8]) {
   DevScene v{};
   fill_view_fields(im, v);
   EngineSelect e;
-  rc = want_wide == -2 ? select_engine_env(v, e) : select_engine(v, want_wide, e);  // -2: as the launches decide, CRT_WIDE included
+  // -2 / -3: as the batched queries' / the renderer's launches decide, CRT_WIDE included; -4: the renderer's own preference
+  const bool renderer = want_wide <= -3;
+  rc = want_wide <= -2 && want_wide != -4 ? select_engine_env(v, e, renderer) : select_engine(v, want_wide == -4 ? -1 : want_wide, e, renderer);
   if (rc != CRT_OK) {
     set_error_text("select_engine: the %s kernels cannot decode this image (direct child words: %s)",
                    want_wide > 0 ? "four-wave" : "three-wave", v.direct_leaves ? "yes" : "no");

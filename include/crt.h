@@ -138,7 +138,8 @@ int crt_scene_image_check(CrtScene *s, uint64_t out[8]);
  * upload — ONE function decides it for the renderer, the batched and the single-ray queries — verified against a census
  * of the image: the instance decodes every child word (the four-wave kernels carry no direct-leaf form) and keeps every
  * rarely used per-ray field some primitive can need. want_wide: -1 = the scene's own preference, 0 / 1 = asked for, -2 =
- * exactly what a launch would pick in this process (the CRT_WIDE A/B request included, which falls back where refused);
+ * exactly what a batched query's launch would pick in this process (the CRT_WIDE A/B request included, which falls back
+ * where refused), -3 = what the renderer's launches would (they differ on large flat trees), -4 = the renderer's preference;
  * CRT_ERR_UNSUPPORTED when what was asked for cannot decode the image (nothing would be launched), CRT_ERR_BAD_ARG +
  * crt_last_error on a broken invariant. out: four-wave kernels | direct-leaf engine copy | LDS stack entries per ray |
  * nodes staged in LDS | cold mask of the per-stage closest-hit kernel | of the fused kernel | direct words in the image |

@@ -355,20 +355,24 @@ def test_gather_plan_of_the_c_abi_assembles_what_the_indexed_stores_do(crt):
         assert np.array_equal(a.cpu().numpy().view(np.uint32), b.numpy().view(np.uint32)), (w, h, world)
 
 
-@pytest.mark.parametrize("env", [{}, {"CRT_FUSED": "0", "CRT_WIDE": "1"}, {"CRT_FUSED": "1"}])
-def test_synthetic_big_identical_to_oracle(crt, env, monkeypatch):
+@pytest.mark.parametrize("env,want", [({"CRT_STAGE_MIN_PATHS": "1"}, (0, 1)), ({"CRT_STAGE_MIN_PATHS": "1", "CRT_WIDE": "0"}, (0, 0)),
+                                      ({"CRT_FUSED": "1"}, (1, 0))])
+def test_synthetic_big_identical_to_oracle(crt, env, want, monkeypatch):
     """The labelled synthetic out-of-cache workload (synthetic.big: 27 tessellated spheres in a closed room under a rect
-    light; here 96 x 48 quads per sphere = 248 832 triangles, the bench runs 512 x 256 = 7.08 M): a large tree — the deep
-    LDS split — through the default pipeline, through the four-wave kernels on their large-tree split (five stack entries,
-    eight-node window, no mask plane) and through the fused kernel: image and all eight counters identical to the oracle."""
+    light; here 96 x 48 quads per sphere = 248 832 triangles, the bench runs 512 x 256 = 7.08 M): a large flat tree. The
+    renderer's own choice for it — one launch per stage on the four-wave kernels with their large-tree split (five stack
+    entries, eight-node window, no mask plane; here forced onto a small batch) —, the three-wave per-stage kernels on the
+    deep split, and the fused kernel: image and all eight counters identical to the oracle."""
     import torch
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     r, desc = crt.load_usda("synthetic:big:96", 96, 54, 6)
-    sel = r.scene.engine_select(-2)
-    assert sel["wide"] == (1 if env.get("CRT_WIDE") == "1" else 0) and sel["lds_stack"] == (5 if sel["wide"] else 10)
+    assert r.scene.engine_select(-4) == dict(r.scene.engine_select(-4), wide=1, direct=0, lds_stack=5, window=8)  # the renderer's preference
+    assert r.scene.engine_select(-1)["wide"] == 0 and r.scene.engine_select(-1)["lds_stack"] == 10              # the batched queries'
     r.render_samples(0, 4)
     torch.cuda.synchronize()
+    p = r.pipeline()
+    assert (int(p["fused"]), int(p["wide"])) == want, p
     img, st = r.image(), r.stats()
     oimg, ost = ora_world.OracleRenderer(desc, crt.usda, max_depth=6).render(4, forward=1)
     for f, _t in ora.RayStats._fields_:
