@@ -162,6 +162,10 @@ struct DevScene {
 // a sphere exists somewhere (its normal is computed at the hit and kept until emit), or instances nest deeper than one
 // level (a hit below the first level is taken to its parent's space at exit). kColdTime: a moving instance exists.
 enum : uint32_t { kColdUV = 1u, kColdNormal = 2u, kColdTime = 4u, kColdAll = 7u };
+// A fourth bit of the KERNELS' cold argument (never of DevScene::cold): the image holds no Tri4 packet at all and carries
+// direct leaf words (a scene of analytic spheres: openpbr_showcase) — the kernel instance then holds ONE engine copy, the
+// direct one, without the packet phase's Woop test and without the per-ray shear constants (traverse_pool.hip.h, NOPK).
+constexpr uint32_t kNoPackets = 8u;
 // Device child words of a node: inner child = node index; leaf child = kLeafTag | leaf index; empty lane =
 // CRT_INVALID_ID. With DevScene::direct_leaves a leaf that holds no Tri4 packet and one to three scalar entries
 // (spheres, instances: every leaf of an instanced city's top-level tree) is written as
@@ -189,6 +193,9 @@ constexpr uint32_t kDirectIndexMask = 0x07ffffffu;
 #endif
 #ifndef CRT_POOL_NODES_DEEP
 #define CRT_POOL_NODES_DEEP 16  // with the deep stack: 16 still fit three workgroups per CU (+0.4 %); 24 do not (-33 %)
+#endif
+#ifndef CRT_NOPK_BUILD
+#define CRT_NOPK_BUILD 1  // 0: no packet-free kernel instances (A/B builds)
 #endif
 #ifndef CRT_DIRECT_LEAVES
 #define CRT_DIRECT_LEAVES 1  // 0: neither written by the upload nor understood by the engine (A/B builds)
@@ -251,17 +258,42 @@ inline int select_engine(const DevScene &s, int want_wide, EngineSelect &e, bool
   const int cold = (int)(s.cold & kColdAll);
   e.ext_cold = cold == 0 ? 0 : (cold == (int)kColdNormal ? (int)kColdNormal : (int)kColdAll);
   e.path_cold = cold == 0 ? 0 : (int)kColdAll;
+  // a packet-free image with direct words: the fused kernel's packet-free instance (general materials; pathtrace.hip)
+  if (CRT_NOPK_BUILD && s.n_packets == 0 && e.direct) e.path_cold = (int)(kColdAll | kNoPackets);
   return CRT_OK;
 }
 // The check every launch site makes on the EngineSelect it was handed (defence in depth: select_engine already
 // guarantees it): the instance can decode every child word of the image and keeps every cold field the image can need.
 inline bool engine_accepts(const EngineSelect &e, const DevScene &s, int kernel_cold) {
   if (s.direct_leaves != 0 && (e.wide || !e.direct)) return false;
+  if ((kernel_cold & (int)kNoPackets) && (s.n_packets != 0 || s.direct_leaves == 0)) return false;  // a packet-free instance on packets
   return ((int)(s.cold & kColdAll) & ~kernel_cold) == 0;
 }
 // CRT_WIDE (A/B runs, tests): 1 asks for the four-wave kernels, 0 for the three-wave ones. A request the image cannot
 // take falls back to the scene's own preference — the knob sweeps whole test sets, direct-leaf scenes included.
 int wide_request();  // -1 unset
+
+// Every A/B knob of the library. The environment is read in ONE place (scene.cpp, read_knobs) — when a scene image is
+// flattened and when a renderer is created — validated and clamped there; nothing else in the library calls getenv.
+// -1 = not set (the library's own choice). None of them changes a result (tests/test_gpu_render.py,
+// test_round3_knobs_change_no_bit); profiles/README.md lists what each was measured for.
+struct Knobs {
+  // scene image (flatten_image)
+  int pool_stack_deep = -1;   // CRT_POOL_STACK_RT: 1 the deep LDS split, 0 the flat one (any value >= 10 / below)
+  int direct_leaves = -1;     // CRT_DIRECT_LEAVES
+  int direct_inst = -1;       // CRT_DIRECT_INST (can only switch the form OFF)
+  int stage_roots = -1;       // CRT_STAGE_ROOTS: at most n instanced roots in the LDS window
+  uint32_t cold = 0;          // CRT_COLD: cold bits the image asks for on top of what it needs (0..7)
+  int inst_order = 1;         // CRT_INST_ORDER
+  int hot_packets = 1;        // CRT_HOT_PACKETS
+  // engine choice
+  int wide = -1;              // CRT_WIDE
+  // renderer
+  int mat_dedup = 1, partition = -1, simple = 1, prefer_stage = -1, cam_compact = 1, shade_wide = -1, fused = -1;
+  int noclassify_from = 1 << 30, tail_from = 12, lanes = 4, grid_mult = 0;
+  size_t max_batch_slots = 0, lane_min_paths = (size_t)96 << 20, stage_min_paths = (size_t)96 << 20;
+};
+Knobs read_knobs();
 inline int select_engine_env(const DevScene &s, EngineSelect &e, bool renderer = false) {
   if (select_engine(s, wide_request(), e, renderer) == CRT_OK) return CRT_OK;
   return select_engine(s, -1, e, renderer);

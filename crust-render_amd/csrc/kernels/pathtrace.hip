@@ -1417,7 +1417,9 @@ struct Renderer {
     // pending normal only / everything for the per-stage k_extend, none / everything for the fused kernel of simple
     // scenes — decided by select_engine, with the image in hand; a launch the image cannot take is refused, never made
     const int ext_cold = d_tstats ? (int)kColdAll : engine.ext_cold;
-    const int path_cold = mats_kind == 0 ? engine.path_cold : (int)kColdAll;
+    // (general material tables run the full-cold fused kernel — or its packet-free instance, for images without a Tri4 packet)
+    const bool nopk = mats_kind != 0 && (engine.path_cold & (int)kNoPackets) != 0;
+    const int path_cold = mats_kind == 0 ? (engine.path_cold & (int)kColdAll) : (int)(kColdAll | (nopk ? kNoPackets : 0u));
     {
       EngineSelect launched = engine;
       launched.wide = wide;  // the fused kernel is a three-wave kernel whatever the scene prefers
@@ -1436,10 +1438,10 @@ struct Renderer {
         switch (mats_kind * 2 + (lit ? 1 : 0)) {
           case 0: if (path_cold == 0) CRT_PATH(0, false, 0); else CRT_PATH(0, false, kColdAll); break;
           case 1: if (path_cold == 0) CRT_PATH(0, true, 0); else CRT_PATH(0, true, kColdAll); break;
-          case 2: CRT_PATH(1, false, kColdAll); break;
-          case 3: CRT_PATH(1, true, kColdAll); break;
-          case 4: CRT_PATH(2, false, kColdAll); break;
-          default: CRT_PATH(2, true, kColdAll); break;
+          case 2: if (nopk) CRT_PATH(1, false, kColdAll | kNoPackets); else CRT_PATH(1, false, kColdAll); break;
+          case 3: if (nopk) CRT_PATH(1, true, kColdAll | kNoPackets); else CRT_PATH(1, true, kColdAll); break;
+          case 4: if (nopk) CRT_PATH(2, false, kColdAll | kNoPackets); else CRT_PATH(2, false, kColdAll); break;
+          default: if (nopk) CRT_PATH(2, true, kColdAll | kNoPackets); else CRT_PATH(2, true, kColdAll); break;
         }
 #undef CRT_PATH
       });
@@ -1461,10 +1463,10 @@ struct Renderer {
           switch (mats_kind * 2 + (lit ? 1 : 0)) {
             case 0: if (path_cold == 0) CRT_TAIL(0, false, 0); else CRT_TAIL(0, false, kColdAll); break;
             case 1: if (path_cold == 0) CRT_TAIL(0, true, 0); else CRT_TAIL(0, true, kColdAll); break;
-            case 2: CRT_TAIL(1, false, kColdAll); break;
-            case 3: CRT_TAIL(1, true, kColdAll); break;
-            case 4: CRT_TAIL(2, false, kColdAll); break;
-            default: CRT_TAIL(2, true, kColdAll); break;
+            case 2: if (nopk) CRT_TAIL(1, false, kColdAll | kNoPackets); else CRT_TAIL(1, false, kColdAll); break;
+            case 3: if (nopk) CRT_TAIL(1, true, kColdAll | kNoPackets); else CRT_TAIL(1, true, kColdAll); break;
+            case 4: if (nopk) CRT_TAIL(2, false, kColdAll | kNoPackets); else CRT_TAIL(2, false, kColdAll); break;
+            default: if (nopk) CRT_TAIL(2, true, kColdAll | kNoPackets); else CRT_TAIL(2, true, kColdAll); break;
           }
 #undef CRT_TAIL
         });
@@ -1548,6 +1550,7 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
   if (scene->p->ensure_device() != CRT_OK) return nullptr;
   CrtRenderer *R = new (std::nothrow) CrtRenderer();
   if (!R) return nullptr;
+  const Knobs knobs = read_knobs();
   Renderer &r = R->r;
   r.scene = scene->p;
   Params &P = r.P;
@@ -1591,7 +1594,7 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
   std::vector<uint16_t> mat_index;
   {
     bool dedup = CRT_MAT_INDEX_BUILD && n_materials > (size_t)mat_lds_max(kArenaDwords);
-    if (const char *e = getenv("CRT_MAT_DEDUP")) dedup = dedup && atoi(e) != 0;
+    dedup = dedup && knobs.mat_dedup != 0;  // CRT_MAT_DEDUP=0
     if (dedup) {
       auto bytes_of = [](const CrtMaterial &m) { return std::string(reinterpret_cast<const char *>(&m), sizeof(CrtMaterial)); };
       std::unordered_map<std::string, uint32_t> seen;
@@ -1624,7 +1627,7 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
     int distinct = 0;
     for (int c = 0; c < kClasses; c++) distinct += seen[c] ? 1 : 0;
     P.partition = distinct > 1 ? 1u : 0u;
-    if (const char *e = getenv("CRT_PARTITION")) P.partition = atoi(e) != 0 ? 1u : 0u;  // A/B runs
+    if (knobs.partition >= 0) P.partition = knobs.partition ? 1u : 0u;  // CRT_PARTITION (A/B runs)
     ok = CRT_HIP_OK(hipMalloc(&r.d_mat_class, n_materials)) &&
          CRT_HIP_OK(hipMemcpy(r.d_mat_class, cls.data(), n_materials, hipMemcpyHostToDevice));
   }
@@ -1650,7 +1653,7 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
   {
     bool simple = true;
     for (size_t k = 0; k < n_materials; k++) simple = simple && material_class(materials[k]) <= 1;
-    if (const char *e = getenv("CRT_SIMPLE")) simple = simple && atoi(e) != 0;  // CRT_SIMPLE=0: the general instance (A/B, tests)
+    simple = simple && knobs.simple != 0;  // CRT_SIMPLE=0: the general instance (A/B, tests)
     r.mats_kind = r.has_media ? 2 : (simple ? 0 : 1);
   }
   P.materials = r.d_materials; P.lights = r.d_lights; P.pixel_index = r.d_pixels;
@@ -1672,20 +1675,20 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
   }
   r.wide = r.engine.wide;
   r.prefer_stage = r.wide || P.scene.pool_stack >= (uint32_t)CRT_POOL_STACK_DEEP;
-  if (const char *e = getenv("CRT_PREFER_STAGE")) r.prefer_stage = atoi(e) != 0;  // A/B runs
-  if (const char *e = getenv("CRT_CAM_COMPACT")) r.cam_compact_ok = atoi(e) != 0;
-  if (const char *e = getenv("CRT_NOCLASSIFY_FROM")) r.noclassify_from = atoi(e);
-  if (const char *e = getenv("CRT_TAIL_FROM")) r.tail_from = atoi(e);
-  if (const char *e = getenv("CRT_MAX_BATCH_SLOTS")) r.max_batch_slots = (size_t)strtoull(e, nullptr, 10);
-  if (const char *e = getenv("CRT_LANES")) { const int n = atoi(e); r.n_lanes = n < 1 ? 1 : (n > Renderer::kMaxLanes ? Renderer::kMaxLanes : n); }
-  if (const char *e = getenv("CRT_LANE_MIN_PATHS")) r.lane_min_paths = (size_t)strtoull(e, nullptr, 10);
-  if (const char *e = getenv("CRT_SHADE_WIDE")) r.shade_wide = atoi(e) != 0 ? 1 : 0;
-  if (const char *e = getenv("CRT_FUSED")) r.force_fused = atoi(e) != 0 ? 1 : 0;
-  if (const char *e = getenv("CRT_STAGE_MIN_PATHS")) r.stage_min_paths = (size_t)strtoull(e, nullptr, 10);
+  if (knobs.prefer_stage >= 0) r.prefer_stage = knobs.prefer_stage != 0;  // the A/B knobs (crt_internal.h, Knobs): CRT_PREFER_STAGE ...
+  r.cam_compact_ok = knobs.cam_compact != 0;
+  r.noclassify_from = knobs.noclassify_from;
+  r.tail_from = knobs.tail_from;
+  r.max_batch_slots = knobs.max_batch_slots;
+  r.n_lanes = knobs.lanes < 1 ? 1 : (knobs.lanes > Renderer::kMaxLanes ? Renderer::kMaxLanes : knobs.lanes);
+  r.lane_min_paths = knobs.lane_min_paths;
+  r.shade_wide = knobs.shade_wide;
+  r.force_fused = knobs.fused;
+  r.stage_min_paths = knobs.stage_min_paths;
   // Workgroups per CU = queue segments per CU: Renderer::batch_grid.
   if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) r.cus = prop.multiProcessorCount;
   r.stage_mult = r.wide ? 8 : 3;
-  if (const char *e = getenv("CRT_GRID_MULT")) { if (atoi(e) > 0) { r.fused_mult = r.stage_mult = atoi(e); r.mult_forced = 1; } }  // tuning knob
+  if (knobs.grid_mult > 0) { r.fused_mult = r.stage_mult = knobs.grid_mult; r.mult_forced = 1; }  // CRT_GRID_MULT: tuning knob
   r.fused = r.force_fused >= 0 ? r.force_fused != 0 : !r.prefer_stage;  // until the first batch: the scene's preference
   r.grid = r.batch_grid(0, r.fused);
   return R;

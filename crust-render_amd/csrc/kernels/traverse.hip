@@ -143,11 +143,6 @@ int grid_for(size_t n, bool wide) {
 
 }  // namespace
 
-int wide_request() {
-  const char *e = getenv("CRT_WIDE");
-  return e ? (atoi(e) != 0 ? 1 : 0) : -1;
-}
-
 int launch_intersect_n(const DevScene &s, const CrtRay *d_rays, size_t n, float t_min, float t_max, CrtRayHit *d_hits,
                        void *stream, CrtTravStats *d_stats, uint32_t *e) {
   if (n == 0) return CRT_OK;

@@ -137,6 +137,9 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
                               uint32_t &err, LaneStats &st, Fetch fetch, Emit emit) {
   const int lane = threadIdx.x & 63;
   constexpr int RL = ROWS * 64;
+  // NOPK (kNoPackets in the kernel's cold argument): the image holds no Tri4 packet — the packet phase only reads the
+  // Leaf record and goes on to its scalar list, no tree ever needs the Woop shear constants
+  constexpr bool NOPK = (COLD & (int)kNoPackets) != 0;
   float4 *f0 = reinterpret_cast<float4 *>(lds);
   float4 *f1 = reinterpret_cast<float4 *>(lds + 4 * RL);
   float2 *f2 = reinterpret_cast<float2 *>(lds + 8 * RL);
@@ -272,7 +275,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
     RayCtx r;
     r.ox = in.ox; r.oy = in.oy; r.oz = in.oz; r.dx = in.dx; r.dy = in.dy; r.dz = in.dz;
     uint32_t kz, swap;
-    store_ray(row, r, S.has_packets != 0, in.t_max, kz, swap);
+    store_ray(row, r, !NOPK && S.has_packets != 0, in.t_max, kz, swap);
     const bool empty = S.root == kInvalid;  // bvh.rs:442-444
     W(W_CTL, row) = ctl_pack(0, 0, 0, S.has_packets ? 1u : 0u, kz, swap, 0);
     W(W_CUR, row) = S.root;
@@ -564,7 +567,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
           }
           const int sl = level > 0 ? 1 : 0;
           if (STATS && k == 0) { st.leaves[sl]++; st.packets[sl] += lf.pkt_count; st.prims[sl] += lf.idx_count; }
-          if (k < lf.pkt_count) {
+          if (!NOPK && k < lf.pkt_count) {
             const uint32_t pki = lf.pkt_first + k;
             // A packet of the staged window is read from LDS (ds_read_b128), the rest from L2; two arms, as for the
             // nodes: merged they become FLAT loads through a generic pointer.
@@ -837,7 +840,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
                 cursor = 0;
                 rem = 0;
                 uint32_t kz, swap;
-                store_ray(row, r, (ih.y & 1u) != 0, closest, kz, swap);
+                store_ray(row, r, !NOPK && (ih.y & 1u) != 0, closest, kz, swap);
                 c = ctl_pack(sp, base, level, ih.y & 1u, kz, swap, 0);
                 push(row, sp, lo, ih.x);
               }
@@ -957,7 +960,7 @@ __device__ void traverse_pool(const DevScene &S, uint32_t *lds /* this wave's po
         r.ox = f.ox; r.oy = f.oy; r.oz = f.oz; r.dx = f.dx; r.dy = f.dy; r.dz = f.dz;
         wr(side_d, row, 0, f.dx); wr(side_d, row, 1, f.dy); wr(side_d, row, 2, f.dz);
         uint32_t kz, swap;
-        store_ray(row, r, f.has_packets != 0, closest, kz, swap);
+        store_ray(row, r, !NOPK && f.has_packets != 0, closest, kz, swap);
         uint32_t cursor = f.cursor;
         uint32_t rem = f.cend;
         next = advance(row, sp, lo, f.base, level, rem, cur, cursor);
@@ -1082,7 +1085,8 @@ __device__ __forceinline__ void run_traversal(const DevScene &S, uint32_t *lds, 
 #define CRT_WIDE_LEAN 1  // the four-wave kernels fetch a packet in stages (LEAN); 0: whole, as the three-wave ones (A/B)
 #endif
 #define CRT_ENGINE(D) traverse_pool<ANY, STATS, CRT_POOL_ROWS, D, (WIDE && CRT_WIDE_LEAN != 0), COLD, UMASK>(S, wave_lds, t_min, umask, lds_nodes, n_lds, n_lds_pk, pstack, err, st, fetch, emit)
-  if (CRT_DIRECT_LEAVES != 0 && !WIDE && S.direct_leaves != 0) CRT_ENGINE(true);
+  if ((COLD & (int)kNoPackets) != 0) CRT_ENGINE(true);  // a packet-free image: the direct engine is the only copy (select_engine)
+  else if (CRT_DIRECT_LEAVES != 0 && !WIDE && S.direct_leaves != 0) CRT_ENGINE(true);
   else CRT_ENGINE(false);
 #undef CRT_ENGINE
 }

@@ -169,6 +169,45 @@ void set_error_text(const char *fmt, ...) {
   va_end(ap);
 }
 
+// The library's only reader of the environment (crt_internal.h, Knobs).
+Knobs read_knobs() {
+  Knobs k;
+  auto num = [](const char *name, long long &out) {
+    const char *e = getenv(name);
+    if (!e || !*e) return false;
+    char *end = nullptr;
+    const long long v = strtoll(e, &end, 10);
+    if (end == e) return false;  // not a number: as if unset
+    out = v;
+    return true;
+  };
+  long long v;
+  if (num("CRT_POOL_STACK_RT", v)) k.pool_stack_deep = v >= CRT_POOL_STACK_DEEP ? 1 : 0;  // a split, not a number the kernels interpret
+  if (num("CRT_DIRECT_LEAVES", v)) k.direct_leaves = v != 0;
+  if (num("CRT_DIRECT_INST", v)) k.direct_inst = v != 0;
+  if (num("CRT_STAGE_ROOTS", v)) k.stage_roots = (int)std::min<long long>(std::max<long long>(v, 0), 1 << 20);
+  if (num("CRT_COLD", v)) k.cold = (uint32_t)v & kColdAll;
+  if (num("CRT_INST_ORDER", v)) k.inst_order = v != 0;
+  if (num("CRT_HOT_PACKETS", v)) k.hot_packets = v != 0;
+  if (num("CRT_WIDE", v)) k.wide = v != 0;
+  if (num("CRT_MAT_DEDUP", v)) k.mat_dedup = v != 0;
+  if (num("CRT_PARTITION", v)) k.partition = v != 0;
+  if (num("CRT_SIMPLE", v)) k.simple = v != 0;
+  if (num("CRT_PREFER_STAGE", v)) k.prefer_stage = v != 0;
+  if (num("CRT_CAM_COMPACT", v)) k.cam_compact = v != 0;
+  if (num("CRT_SHADE_WIDE", v)) k.shade_wide = v != 0;
+  if (num("CRT_FUSED", v)) k.fused = v != 0;
+  if (num("CRT_NOCLASSIFY_FROM", v)) k.noclassify_from = (int)std::min<long long>(std::max<long long>(v, 0), 1 << 30);
+  if (num("CRT_TAIL_FROM", v)) k.tail_from = (int)std::min<long long>(std::max<long long>(v, 0), 1 << 30);
+  if (num("CRT_LANES", v)) k.lanes = (int)std::min<long long>(std::max<long long>(v, 1), 4);
+  if (num("CRT_GRID_MULT", v)) k.grid_mult = (int)std::min<long long>(std::max<long long>(v, 0), 64);
+  if (num("CRT_MAX_BATCH_SLOTS", v)) k.max_batch_slots = v > 0 ? (size_t)v : 0;
+  if (num("CRT_LANE_MIN_PATHS", v)) k.lane_min_paths = v > 0 ? (size_t)v : 1;
+  if (num("CRT_STAGE_MIN_PATHS", v)) k.stage_min_paths = v > 0 ? (size_t)v : 1;
+  return k;
+}
+int wide_request() { return read_knobs().wide; }
+
 int device_ok() {
   static int ok = [] {
     int n = 0;
@@ -234,8 +273,7 @@ Flat::Placed place(Flat &f, const Scene &s) {
   std::vector<uint32_t> inst_slot(b.prims.size(), CRT_INVALID_ID);
   {
     uint32_t next_slot = uint32_t(f.instances.size());
-    static const bool list_order = [] { const char *e = getenv("CRT_INST_ORDER"); return !e || atoi(e) != 0; }();  // A/B runs
-    if (list_order)
+    if (read_knobs().inst_order)  // CRT_INST_ORDER=0: primitive order (A/B runs)
     for (uint32_t i : b.indices)
       if (b.prims[i].kind == PRIM_INSTANCE && inst_slot[i] == CRT_INVALID_ID) inst_slot[i] = next_slot++;
     for (size_t i = 0; i < b.prims.size(); i++)  // on no list (cannot happen with this builder): still gets a record
@@ -327,8 +365,8 @@ int flatten_image(const Scene &scene, FlatImage &im) {
     // ... and among the queried tree's packets, the leaves a ray is most likely to reach first: by the surface area of
     // the leaf's box (the SAH's hit probability), largest first — the walls of a room before the detail inside it. Only
     // the first packets fit the window; a leaf's packets stay consecutive. CRT_HOT_PACKETS=0: builder order (A/B).
-    static const bool hot_first = [] { const char *e = getenv("CRT_HOT_PACKETS"); return !e || atoi(e) != 0; }();
-    if (hot_first && n_top > 1) {
+    const Knobs knobs = read_knobs();
+    if (knobs.hot_packets && n_top > 1) {
       std::vector<std::pair<float, uint32_t>> order;  // (-area, leaf)
       for (const WideNode &n : f.nodes)
         for (int l = 0; l < 4; l++) {
@@ -361,7 +399,8 @@ int flatten_image(const Scene &scene, FlatImage &im) {
   const bool large_tree = f.nodes.size() > 2048;
   uint32_t pool_stack = (many_instances || large_tree) ? 10u : 6u;
   // A/B runs: the split, not a number — anything from the deep split's entry count up is the deep one, all else the flat
-  if (const char *e = getenv("CRT_POOL_STACK_RT")) pool_stack = atoi(e) >= CRT_POOL_STACK_DEEP ? (uint32_t)CRT_POOL_STACK_DEEP : (uint32_t)CRT_POOL_STACK;
+  const Knobs knobs = read_knobs();
+  if (knobs.pool_stack_deep >= 0) pool_stack = knobs.pool_stack_deep ? (uint32_t)CRT_POOL_STACK_DEEP : (uint32_t)CRT_POOL_STACK;
   im.pool_stack = pool_stack;
   const bool deep = pool_stack >= 10u;  // run_traversal's rule for the window size
   // Renumber the nodes for the window the kernels stage in LDS (the first nodes of the array; 72 / 16 / 26 of them
@@ -399,7 +438,7 @@ int flatten_image(const Scene &scene, FlatImage &im) {
     }
     const size_t window = deep ? CRT_POOL_NODES_DEEP : std::min<size_t>(CRT_POOL_NODES, CRT_POOL_NODES_WIDE);
     size_t n_staged_roots = std::min(inner_roots.size(), window / 2);
-    if (const char *e = getenv("CRT_STAGE_ROOTS")) n_staged_roots = std::min(n_staged_roots, (size_t)atoi(e));  // A/B runs
+    if (knobs.stage_roots >= 0) n_staged_roots = std::min(n_staged_roots, (size_t)knobs.stage_roots);  // A/B runs
     im.n_staged_roots = uint32_t(n_staged_roots);
     if (me.root != CRT_INVALID_ID) number(me.root);
     for (size_t k = 0; k < n_staged_roots; k++) number(inner_roots[k].second);
@@ -426,11 +465,11 @@ int flatten_image(const Scene &scene, FlatImage &im) {
     return CRT_ERR_UNSUPPORTED;
   }
   bool direct = many_instances || f.packets.empty();
-  if (const char *e = getenv("CRT_DIRECT_LEAVES")) direct = atoi(e) != 0;  // A/B runs
+  if (knobs.direct_leaves >= 0) direct = knobs.direct_leaves != 0;  // A/B runs
   if (!CRT_DIRECT_LEAVES) direct = false;  // an engine built without the direct form must never meet one
   im.direct = direct;
   bool direct_inst = CRT_DIRECT_INST != 0;
-  if (const char *e = getenv("CRT_DIRECT_INST")) direct_inst = direct_inst && atoi(e) != 0;  // A/B runs
+  if (knobs.direct_inst >= 0) direct_inst = direct_inst && knobs.direct_inst != 0;  // A/B runs
   im.leaf_of_word.assign(f.nodes.size() * 4, CRT_INVALID_ID);
   for (size_t ni = 0; ni < f.nodes.size(); ni++) {
     WideNode &n = f.nodes[ni];
@@ -467,7 +506,7 @@ int flatten_image(const Scene &scene, FlatImage &im) {
     }
     if (instance_levels(scene) > 1) cold |= kColdNormal;
     if (!f.moving.empty()) cold |= kColdTime;
-    if (const char *e = getenv("CRT_COLD")) cold |= (uint32_t)atoi(e) & kColdAll;
+    cold |= knobs.cold;  // CRT_COLD
     im.cold = cold;
   }
   // placements of the moving instances: behind the shading normals, addressed through the instance's flags word

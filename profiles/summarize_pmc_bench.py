@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Writes profiles/r03_pmc_bench.json — what bench.py reports as roofline.traffic / hbm_measured_frac / l2_hit /
-valu_issue_frac, per kernel of the pipeline — from PMC passes collected with profiles/run_pmc_r02.sh:
+"""Writes profiles/r04_pmc_bench.json — what bench.py reports as roofline.traffic / hbm_measured_frac / l2_hit /
+valu_issue_frac, per kernel of the pipeline — from PMC passes collected with profiles/run_pmc_r04.sh:
     python profiles/summarize_pmc_bench.py "<workload key>=<tag>" ...      e.g. "cornellbox 1920x1080 256spp=cb"
 Each tag names gpurun_out/pmc_<tag>_<pass>/; the workload key is bench.py's (`<scene> <w>x<h> <spp per step>spp`).
 Per workload one entry per kernel FAMILY the run launched (k_path, k_extend, k_shade, k_shadow, k_generate): of a
@@ -13,12 +13,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import kernel_source_hash  # noqa: E402
 
-OUT = os.path.join(ROOT, "profiles", "r03_pmc_bench.json")
+OUT = os.path.join(ROOT, "profiles", "r04_pmc_bench.json")
 FAMILIES = ("k_path", "k_extend", "k_shade", "k_shadow", "k_generate")
 
 out = {"kernel_source_hash": kernel_source_hash(),
        "git_commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip() or "?",
-       "collected_with": "bash profiles/run_pmc_r02.sh <tag> bench.py --no-cpu-baseline ... (separate rocprofv3 --kernel-trace --pmc passes); "
+       "collected_with": "bash profiles/run_pmc_r04.sh <tag> bench.py --no-cpu-baseline ... (separate rocprofv3 --kernel-trace --pmc passes); "
                          "traffic = TCC_EA0_RDREQ_DRAM_32B_sum x 32 B + TCC_EA0_WRREQ_WRITE_DRAM_32B_sum x 32 B (calibration: profiles/r02_pmc_calibration.json)",
        "workloads": {}}
 if os.path.exists(OUT) and "--merge" in sys.argv:  # keep the workloads of an earlier call on the same build

@@ -54,3 +54,32 @@ def test_no_product_module_touches_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 for needle in ("liboracle", "import ora", '#include "ora', "oracle/_build", "-loracle"):
                     assert needle not in text, (os.path.join(dirpath, f), needle)
+
+
+def test_the_library_reads_the_environment_in_one_place():
+    """Every A/B knob goes through crt::read_knobs (csrc/scene.cpp; crt_internal.h, Knobs): validated and clamped there.
+    Nothing else under csrc/ calls getenv (21 call sites in the scene / renderer set-up paths, one of
+    which took any integer)."""
+    import re
+    csrc = os.path.join(ROOT, "crust-render_amd", "csrc")
+    sites = []
+    for dirpath, _, files in os.walk(csrc):
+        if os.path.basename(dirpath).startswith("_obj"):
+            continue
+        for f in files:
+            if f.endswith((".cpp", ".h", ".hip")):
+                for n, line in enumerate(open(os.path.join(dirpath, f), errors="ignore"), 1):
+                    if re.search(r"\bgetenv\s*\(", line) and not line.lstrip().startswith("//"):
+                        sites.append((f, n))
+    assert len(sites) == 1 and sites[0][0] == "scene.cpp", sites
+
+
+def test_shading_seam_records_have_the_sizes_the_header_states(crt):
+    import ctypes as C
+    sh = crt.shading
+    assert (sh.SHADE_QUERY.itemsize, sh.SCATTER_SAMPLE.itemsize, sh.BSDF_EVAL.itemsize, sh.LIGHT_QUERY.itemsize,
+            sh.LIGHT_SAMPLE.itemsize) == (80, 48, 32, 48, 48)
+    assert C.sizeof(crt.CrtMaterial) == 224 and C.sizeof(crt.CrtLight) == 84
+    # host-only entry points of the round: the padded tile count needs no device
+    assert crt.shard.padded_count(1920, 1080, 8) == crt.lib().crt_shard_padded_count(1920, 1080, 8) > 0
+    assert crt.shard.padded_count(1920, 1080, 8) % 256 == 0 and crt.shard.padded_count(1920, 1080, 8) >= crt.shard.shard_pixels(1920, 1080, 0, 8).size
