@@ -195,7 +195,10 @@ constexpr uint32_t kDirectIndexMask = 0x07ffffffu;
 #define CRT_POOL_NODES_DEEP 16  // with the deep stack: 16 still fit three workgroups per CU (+0.4 %); 24 do not (-33 %)
 #endif
 #ifndef CRT_NOPK_BUILD
-#define CRT_NOPK_BUILD 1  // 0: no packet-free kernel instances (A/B builds)
+// 1: packet-free instances of the fused kernel for images without a Tri4 packet (kNoPackets). Measured on openpbr_showcase
+// (round 4): one engine copy and 13 % fewer instructions, but 53 -> 67 spilled registers in k_path<2, true, .>: 12 294 ->
+// 12 176 Mray/s. Off; the switch stays for A/B builds.
+#define CRT_NOPK_BUILD 0
 #endif
 #ifndef CRT_DIRECT_LEAVES
 #define CRT_DIRECT_LEAVES 1  // 0: neither written by the upload nor understood by the engine (A/B builds)

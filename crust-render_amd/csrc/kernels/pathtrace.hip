@@ -1435,14 +1435,20 @@ struct Renderer {
       timed(0, st, [&] {
 #define CRT_PATH(M, L, CO) \
   hipLaunchKernelGGL((k_path<M, L, CO>), dim3(grid), dim3(kBlock), 0, st, p, S[0], S[1], H, Q, C, staging, sample_begin, n_samples, 0u, 0)
+#if CRT_NOPK_BUILD  // the packet-free instances exist only in builds that ask for them (A/B: profiles/README.md, round 4)
+#define CRT_PATH_NP(M, L) do { if (nopk) CRT_PATH(M, L, kColdAll | kNoPackets); else CRT_PATH(M, L, kColdAll); } while (0)
+#else
+#define CRT_PATH_NP(M, L) CRT_PATH(M, L, kColdAll)
+#endif
         switch (mats_kind * 2 + (lit ? 1 : 0)) {
           case 0: if (path_cold == 0) CRT_PATH(0, false, 0); else CRT_PATH(0, false, kColdAll); break;
           case 1: if (path_cold == 0) CRT_PATH(0, true, 0); else CRT_PATH(0, true, kColdAll); break;
-          case 2: if (nopk) CRT_PATH(1, false, kColdAll | kNoPackets); else CRT_PATH(1, false, kColdAll); break;
-          case 3: if (nopk) CRT_PATH(1, true, kColdAll | kNoPackets); else CRT_PATH(1, true, kColdAll); break;
-          case 4: if (nopk) CRT_PATH(2, false, kColdAll | kNoPackets); else CRT_PATH(2, false, kColdAll); break;
-          default: if (nopk) CRT_PATH(2, true, kColdAll | kNoPackets); else CRT_PATH(2, true, kColdAll); break;
+          case 2: CRT_PATH_NP(1, false); break;
+          case 3: CRT_PATH_NP(1, true); break;
+          case 4: CRT_PATH_NP(2, false); break;
+          default: CRT_PATH_NP(2, true); break;
         }
+#undef CRT_PATH_NP
 #undef CRT_PATH
       });
       return fold();
@@ -1460,14 +1466,20 @@ struct Renderer {
         timed(3, st, [&] {
 #define CRT_TAIL(M, L, CO) \
   hipLaunchKernelGGL((k_path<M, L, CO>), dim3(grid), dim3(kBlock), 0, st, p, S[0], S[1], H, Q, C, staging, sample_begin, n_samples, it, cur)
+#if CRT_NOPK_BUILD
+#define CRT_TAIL_NP(M, L) do { if (nopk) CRT_TAIL(M, L, kColdAll | kNoPackets); else CRT_TAIL(M, L, kColdAll); } while (0)
+#else
+#define CRT_TAIL_NP(M, L) CRT_TAIL(M, L, kColdAll)
+#endif
           switch (mats_kind * 2 + (lit ? 1 : 0)) {
             case 0: if (path_cold == 0) CRT_TAIL(0, false, 0); else CRT_TAIL(0, false, kColdAll); break;
             case 1: if (path_cold == 0) CRT_TAIL(0, true, 0); else CRT_TAIL(0, true, kColdAll); break;
-            case 2: if (nopk) CRT_TAIL(1, false, kColdAll | kNoPackets); else CRT_TAIL(1, false, kColdAll); break;
-            case 3: if (nopk) CRT_TAIL(1, true, kColdAll | kNoPackets); else CRT_TAIL(1, true, kColdAll); break;
-            case 4: if (nopk) CRT_TAIL(2, false, kColdAll | kNoPackets); else CRT_TAIL(2, false, kColdAll); break;
-            default: if (nopk) CRT_TAIL(2, true, kColdAll | kNoPackets); else CRT_TAIL(2, true, kColdAll); break;
+            case 2: CRT_TAIL_NP(1, false); break;
+            case 3: CRT_TAIL_NP(1, true); break;
+            case 4: CRT_TAIL_NP(2, false); break;
+            default: CRT_TAIL_NP(2, true); break;
           }
+#undef CRT_TAIL_NP
 #undef CRT_TAIL
         });
         break;
@@ -1674,7 +1686,9 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
     return nullptr;
   }
   r.wide = r.engine.wide;
-  r.prefer_stage = r.wide || P.scene.pool_stack >= (uint32_t)CRT_POOL_STACK_DEEP;
+  // ... and, once lanes overlap a batch's launches, every scene: the sphere-only showcase 12 176 -> 13 078 Mray/s (+7.4 %;
+  // round 2, one stream: -1 %). The fused kernel remains what small batches and the tails of large ones run.
+  r.prefer_stage = true;
   if (knobs.prefer_stage >= 0) r.prefer_stage = knobs.prefer_stage != 0;  // the A/B knobs (crt_internal.h, Knobs): CRT_PREFER_STAGE ...
   r.cam_compact_ok = knobs.cam_compact != 0;
   r.noclassify_from = knobs.noclassify_from;

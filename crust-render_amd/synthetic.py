@@ -130,8 +130,9 @@ def big(width=640, height=360, side=512, max_depth=6):
     north_star's ">= 40 % of HBM peak in the traversal kernel" is physically reachable only on a scene like this
     (SURVEY §8d). side = 128 (442 368 triangles) is the size the parity tests render against the oracle."""
     d = usda.SceneDesc()
-    # bright looks (albedo 0.8-0.9): Russian roulette (tracer.rs:1478-1490) then keeps most paths to the depth limit, so a
-    # batch's closest-hit launches are mostly incoherent bounce rays, not the coherent camera rays of bounce 0
+    # bright looks (albedo 0.8-0.9). Paths still thin out fast from the fourth vertex on: the reference's convention
+    # `value = brdf * cos` with the tracer multiplying by the cosine again (material.rs:10-12) takes a mean factor of
+    # albedo * 2/3 per diffuse bounce, and Russian roulette (tracer.rs:1478-1490) follows the throughput
     looks = [
         {"base_color": (0.90, 0.82, 0.80), "specular_weight": 0.0},
         {"base_color": (0.80, 0.90, 0.82), "specular_weight": 0.0},

@@ -1,12 +1,13 @@
 #!/bin/bash
 # Round-4 evidence on the shipped build, in calls of < 20 minutes each (gpurun's limit):
-#   bash profiles/evidence_r04.sh <tag> 1   GPU tests; PMC passes of the bench scene, the stress scene and the synthetic 7 M-triangle
-#                                           scene -> r04_pmc_bench.json (written on the box, on the profiled build)
-#   bash profiles/evidence_r04.sh <tag> 2   PMC passes of veach_mis, openpbr_showcase, MedCity 4K (merged into the same file: needs
-#                                           part 1's gpurun_out/<tag>_pmc_bench.json copied to profiles/r04_pmc_bench.json first);
-#                                           the bench line (headline + other_configs + both CPU baselines); the synthetic scene's line
-#   bash profiles/evidence_r04.sh <tag> 3   rocprofv3 --kernel-trace --stats of bench.py; kernel probe (+ the 7 M-triangle scene);
+#   bash profiles/evidence_r04.sh <tag> 1   GPU tests; PMC passes of the bench scene and the stress scene -> r04_pmc_bench.json (written on
+#                                           the box, on the profiled build)
+#   bash profiles/evidence_r04.sh <tag> 2   PMC passes of the synthetic 7 M-triangle scene (+ its per-launch table), veach_mis, openpbr_showcase
+#   bash profiles/evidence_r04.sh <tag> 3   PMC passes of MedCity 4K; the bench line (headline + other_configs + both CPU baselines); the
+#                                           synthetic scene's and the stress scene's lines
+#   bash profiles/evidence_r04.sh <tag> 4   rocprofv3 --kernel-trace --stats of bench.py; kernel probe (+ the 7 M-triangle scene);
 #                                           published renders; per-bounce work; the N = 4 gloo rehearsal at configs 4 and 5's shapes
+# Parts 2 and 3 merge into the r04_pmc_bench.json of the SAME build: copy gpurun_out/<tag>_pmc_bench.json to profiles/ between calls.
 T=$1; PART=$2; R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 stats() { # name, bench args...
   local n=$1; shift
@@ -17,16 +18,19 @@ case $PART in
 1)
   timeout -k 10 900 python -m pytest tests -m gpu -q -p no:cacheprovider > gpurun_out/${T}_tests.log 2>&1; echo "pytest rc=$?"; tail -2 gpurun_out/${T}_tests.log
   rm -f profiles/r04_pmc_bench.json
-  bash profiles/pmc_r04.sh $T cb stress big
-  python profiles/pmc_per_launch.py ${T}big k_extend k_shadow > gpurun_out/${T}_pmc_per_launch_big.json
+  bash profiles/pmc_r04.sh $T cb stress
   ;;
 2)
-  bash profiles/pmc_r04.sh $T veach showcase mc
+  bash profiles/pmc_r04.sh $T big veach showcase
+  python profiles/pmc_per_launch.py ${T}big k_extend k_shadow > gpurun_out/${T}_pmc_per_launch_big.json
+  ;;
+3)
+  bash profiles/pmc_r04.sh $T mc
   python bench.py > gpurun_out/${T}_bench_default.json 2> gpurun_out/${T}_bench.err
   python bench.py --no-cpu-baseline --no-other-configs --scene synthetic:big --spp-per-step 128 --steps 2 --warmup 1 > gpurun_out/${T}_bench_big.json 2>> gpurun_out/${T}_bench.err
   python bench.py --no-other-configs --scene stress --spp-per-step 256 --steps 2 --warmup 1 > gpurun_out/${T}_bench_stress.json 2>> gpurun_out/${T}_bench.err
   ;;
-3)
+4)
   stats bench_default
   stats big --scene synthetic:big --spp-per-step 128 --steps 2 --warmup 1
   python bench_kernels.py > gpurun_out/${T}_kernel_probe.json 2> gpurun_out/${T}_kernel_probe.err

@@ -196,7 +196,7 @@ def test_the_three_pipelines_agree(crt, tmp_path, scene, w, h, depth):
     for tag, env, want in (("fused", dict(CRT_FUSED="1"), (1, 0, 1)), ("stage3", dict(CRT_FUSED="0", CRT_WIDE="0"), (0, 0, 0)),
                            ("stage4", dict(CRT_FUSED="0", CRT_WIDE="1"), (0, wide, 0)),
                            # the batch decides: 5 spp of every pixel reach the threshold, 3 do not
-                           ("by_batch", dict(CRT_WIDE="1", CRT_STAGE_MIN_PATHS=str(w * h * 4)), (0 if wide else 1, wide, 1))):
+                           ("by_batch", dict(CRT_WIDE="1", CRT_STAGE_MIN_PATHS=str(w * h * 4)), (0, wide, 1))):
         path = str(tmp_path / ("img_%s.npy" % tag))
         res = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True, text=True,
                              timeout=300)
