@@ -368,15 +368,17 @@ int crt_render_stats(CrtRenderer *r, CrtRayStats *out);
 int crt_renderer_shade_class_stats(CrtRenderer *r, int enable, uint64_t out_waves[4], uint64_t out_lanes[4]);
 /* The launch pipeline of the last batch rendered (before the first: the scene's preference): out[0] = 1 fused (one
  * launch runs generate and every bounce's extend, shade and shadow stage of the batch), 0 one launch per stage and
- * bounce; out[1] = 1 when the traversal kernels are the four-workgroups-per-CU instances; out[2] = workgroups (= queue
- * segments) per launch. The renderer takes the per-stage form for batches of >= 96 Mi paths of small flat triangle
- * scenes and the fused kernel otherwise (instance-heavy or sphere-only scenes, small batches). Environment CRT_FUSED /
- * CRT_WIDE / CRT_STAGE_MIN_PATHS / CRT_GRID_MULT override. */
+ * bounce; out[1] = 1 when the traversal kernels are the four-workgroups-per-CU instances (flat triangle scenes: small
+ * trees and, in the renderer, large ones; crt_scene_engine_select); out[2] = workgroups (= queue segments) per launch.
+ * The renderer takes the per-stage form for batches of >= 96 Mi paths and the fused kernel for smaller ones and for the
+ * tail of a large one. Environment CRT_FUSED / CRT_WIDE / CRT_STAGE_MIN_PATHS / CRT_GRID_MULT override. */
 int crt_renderer_pipeline(const CrtRenderer *r, uint32_t out[3]);
-/* Lanes of the last batch rendered (1 before the first): a batch of at least 2 x 96 Mi paths runs as 2 (CRT_LANES, up to
- * 4) sub-batches of consecutive samples, each with its own buffers and counters on its own HIP stream, so one
- * sub-batch's launches overlap the other's; the film fold stays on the caller's stream, lane after lane — samples are
- * summed in the order of one batch and the image bits do not depend on the lane count (tests/test_gpu_render.py).
+/* Lanes of the last batch rendered (1 before the first): a batch runs as up to 4 (the default; CRT_LANES) sub-batches of
+ * consecutive samples — as many as keep 96 Mi paths each (CRT_LANE_MIN_PATHS) — each with its own buffers and counters on
+ * its own HIP stream, so one sub-batch's launches overlap the others'; the film fold stays on the caller's stream, lane
+ * after lane — samples are summed in the order of one batch and the image bits do not depend on the lane count
+ * (tests/test_gpu_render.py). Every lane's buffers are allocated before any lane launches; a failure after that drains
+ * the lanes' streams before it is reported.
  * No reference counterpart (the reference renders tiles on Rayon workers, tracer.rs:424-459). */
 int crt_renderer_lanes(const CrtRenderer *r);
 /* Live HIP-event timing of the kernels launched by crt_render_samples since the last reset, by class:

@@ -142,3 +142,53 @@ def test_scene_is_imported_once_and_ray_stats_are_reduced_gloo(tmp_path):
     assert d[0] == d[1] and d[0]["geoms"] > 0 and d[0]["lights"] > 0
     s = [pickle.load(open(os.path.join(str(tmp_path), "stats%d.pkl" % r), "rb")) for r in range(2)]
     assert s[0] == s[1] == [3 * 10 ** k + (2 << 40) * (k == 1) for k in range(8)]
+
+
+def _worker_fit_batch(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import bench
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    class Err(RuntimeError):
+        pass
+
+    class FakeCrt:
+        CrtError = Err
+
+    class FakeRenderer:  # allocates up to `limit` samples per batch: the ranks of a node need not have the same free HBM
+        def __init__(self, limit):
+            self.limit, self.calls, self.cleared = limit, [], 0
+
+        def render_samples(self, begin, count, stream):
+            self.calls.append(count)
+            if count > self.limit:
+                raise Err("out of memory")
+
+        def clear(self, stream):
+            self.cleared += 1
+
+    r = FakeRenderer(8 if rank == 0 else 64)  # per job sample counts (spp_per_step x world): rank 0 fits 8, rank 1 fits 64
+    got = bench.fit_batch(FakeCrt, r, 32, world, None, dist, "cpu")
+    with open(os.path.join(out_dir, "fit%d.txt" % rank), "w") as f:
+        f.write("%d %s %d" % (got, ",".join(map(str, r.calls)), r.cleared))
+    dist.destroy_process_group()
+
+
+def test_ranks_agree_on_the_smallest_batch_any_of_them_fits(tmp_path):
+    """bench.py's halving fallback with N > 1: every rank halves on its own until ITS batch fits, then one
+    all-reduce(MIN) makes all of them run the smallest shape — rank 0 (32 -> 16 -> 8 -> 4 spp per share at world 2) and
+    rank 1 (32 at once) both come out at 4 — and the probe's samples are cleared on every rank."""
+    import torch.multiprocessing as mp
+    port = 29500 + ((os.getpid() + 911) % 2000)
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker_fit_batch, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    a = open(os.path.join(str(tmp_path), "fit0.txt")).read().split()
+    b = open(os.path.join(str(tmp_path), "fit1.txt")).read().split()
+    assert a[0] == b[0] == "4" and a[1] == "64,32,16,8" and b[1] == "64" and a[2] == b[2] == "1"
