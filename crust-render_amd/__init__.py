@@ -165,7 +165,7 @@ ABI_SYMBOLS = [
     "crt_material_scatter_n", "crt_material_eval_n", "crt_material_emitted_n", "crt_light_sample_n", "crt_light_pdf_n",
     "crt_light_escaped_n",
     "crt_shard_padded_count", "crt_gather_plan_new", "crt_gather_plan_free", "crt_gather_plan_padded_count",
-    "crt_gather_plan_assemble",
+    "crt_gather_plan_assemble", "crt_renderer_set_lanes",
 ]
 
 _lib = None
@@ -251,6 +251,8 @@ def lib():
         if hasattr(L, "crt_renderer_lanes"):  # absent from older A/B variant libraries
             L.crt_renderer_lanes.argtypes = [vp]
             L.crt_renderer_lanes.restype = C.c_int
+        if hasattr(L, "crt_renderer_set_lanes"):  # absent from older A/B variant libraries
+            L.crt_renderer_set_lanes.argtypes = [vp, C.c_int]
         if hasattr(L, "crt_renderer_pipeline"):  # absent from older A/B variant libraries
             L.crt_renderer_pipeline.argtypes = [vp, C.POINTER(C.c_uint32)]
         if hasattr(L, "crt_renderer_shade_class_stats"):  # absent from older A/B variant libraries
@@ -731,6 +733,10 @@ class Renderer:
     def lanes(self):
         """Sub-batches (own buffers, own HIP stream) the last batch ran as (crt.h, crt_renderer_lanes)."""
         return int(lib().crt_renderer_lanes(self.h)) if hasattr(lib(), "crt_renderer_lanes") else 1
+
+    def set_lanes(self, lanes):
+        """Lanes later batches may run as (1..4; crt.h, crt_renderer_set_lanes). Returns the count set."""
+        return _check(lib().crt_renderer_set_lanes(self.h, int(lanes)), "crt_renderer_set_lanes")
 
     def profile(self, enable=True):
         _check(lib().crt_renderer_profile(self.h, 1 if enable else 0), "crt_renderer_profile")

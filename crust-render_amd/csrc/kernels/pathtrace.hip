@@ -1813,6 +1813,11 @@ int crt_renderer_shade_class_stats(CrtRenderer *r, int enable, uint64_t out_wave
   return CRT_OK;
 }
 int crt_renderer_lanes(const CrtRenderer *r) { return r ? r->r.last_lanes : 0; }
+int crt_renderer_set_lanes(CrtRenderer *r, int lanes) {
+  if (!r) return CRT_ERR_BAD_ARG;
+  r->r.n_lanes = lanes < 1 ? 1 : (lanes > Renderer::kMaxLanes ? Renderer::kMaxLanes : lanes);
+  return r->r.n_lanes;
+}
 int crt_renderer_pipeline(const CrtRenderer *r, uint32_t out[3]) {
   if (!r || !out) return CRT_ERR_BAD_ARG;
   out[0] = r->r.fused ? 1u : 0u;

@@ -381,6 +381,9 @@ int crt_renderer_pipeline(const CrtRenderer *r, uint32_t out[3]);
  * the lanes' streams before it is reported.
  * No reference counterpart (the reference renders tiles on Rayon workers, tracer.rs:424-459). */
 int crt_renderer_lanes(const CrtRenderer *r);
+/* How many lanes later batches may run as: 1 .. 4 (values outside are clamped); returns the count set. A measurement
+ * tool asks for 1 to time every launch alone on the chip (bench.py's roofline legs); results do not depend on it. */
+int crt_renderer_set_lanes(CrtRenderer *r, int lanes);
 /* Live HIP-event timing of the kernels launched by crt_render_samples since the last reset, by class:
  * 0 = extend (closest-hit traversal) — or, in the fused pipeline, the path-loop kernel that runs generate, extend,
  * shade and shadow of a whole batch in one launch — 1 = shade, 2 = shadow (occlusion traversal), 3 = other.

@@ -30,7 +30,8 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     # the bound is the tier the bytes are served from (bench.py, _roofline_entry): never a fraction above 1 of "hbm"
     assert r["bound"] in ("hbm", "latency/issue") and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["peak"] == (8000.0 if r["bound"] == "hbm" else 34500.0) and (r["bound"] != "hbm" or r["frac"] <= 1.0)
-    assert abs(r["hbm_frac_algorithmic"] - r["achieved"] / 8000.0) < 1e-3 and abs(r["l2_frac"] - r["achieved"] / 34500.0) < 1e-3
+    assert abs(r["hbm_frac_algorithmic"] - r["algorithmic_gb_s"] / 8000.0) < 1e-3 and abs(r["l2_frac"] - r["algorithmic_gb_s"] / 34500.0) < 1e-3
+    assert r["frac"] <= 1.0 or r["bound"] != "hbm"  # never more than the peak of the bound it names
     for k, e in r["kernels"].items():  # the other stages of a per-stage pipeline, same fields
         assert k in ("k_extend", "k_shade", "k_shadow") and e["avg_launch_ms"] > 0 and e["achieved"] > 0
     c = d["cpu_baseline"]
@@ -188,6 +189,13 @@ def test_roofline_entry_names_the_tier_that_serves_the_bytes(monkeypatch):
     monkeypatch.setattr(bench, "_pmc_for", lambda key, kernel: (entry2, "fake"))
     h = bench._roofline_entry("k_shade", 40.0e9, 6.8 * 24, 24, 2, "w", 1)
     assert h["bound"] == "hbm" and h["peak"] == bench.HBM_PEAK_GBS and h["frac"] <= 1.0
+    # an HBM-bound kernel whose caches serve part of its algorithmic bytes (the 7 M-triangle scene's traversal: 10 TB/s
+    # algorithmic, 0.35 of the peak measured): priced on the bytes that crossed the fabric, never above the peak
+    entry3 = dict(entry, ea_dram_read_bytes_per_launch=99.8e9, ea_dram_write_bytes_per_launch=8.0e9)
+    monkeypatch.setattr(bench, "_pmc_for", lambda key, kernel: (entry3, "fake"))
+    b = bench._roofline_entry("k_extend", 384.0e9, 38.2 * 14, 14, 2, "w", 1)
+    assert b["bound"] == "hbm" and b["frac"] <= 1.0 and abs(b["frac"] - b["hbm_measured_frac"]) < 1e-3
+    assert b["hbm_frac_algorithmic"] > 1.0 and "measured" in b["achieved_basis"] and abs(b["frac"] - b["achieved"] / b["peak"]) < 1e-3
     # no PMC passes for this build: decided from the algorithmic rate alone
     monkeypatch.setattr(bench, "_pmc_for", lambda key, kernel: (None, "none"))
     n = bench._roofline_entry("k_extend", 160.0e9, 12.8 * 24, 24, 2, "w", 1)
