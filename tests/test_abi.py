@@ -83,3 +83,18 @@ def test_shading_seam_records_have_the_sizes_the_header_states(crt):
     # host-only entry points of the round: the padded tile count needs no device
     assert crt.shard.padded_count(1920, 1080, 8) == crt.lib().crt_shard_padded_count(1920, 1080, 8) > 0
     assert crt.shard.padded_count(1920, 1080, 8) % 256 == 0 and crt.shard.padded_count(1920, 1080, 8) >= crt.shard.shard_pixels(1920, 1080, 0, 8).size
+
+
+def test_shading_seam_argument_checks_need_no_device(crt):
+    """The seam's entry points validate their arguments before they touch a device: nothing to do is CRT_OK, a missing
+    query / result pointer is CRT_ERR_BAD_ARG (and, on a box without a gfx950 device, anything else CRT_ERR_NO_DEVICE —
+    there is no CPU fallback behind the ABI)."""
+    L = crt.lib()
+    for name in ("crt_material_scatter_n", "crt_material_eval_n", "crt_material_emitted_n", "crt_light_sample_n",
+                 "crt_light_pdf_n", "crt_light_escaped_n"):
+        f = getattr(L, name)
+        assert f(None, 0, None, 0, None, None) == 0                      # n == 0
+        assert f(None, 0, None, 5, None, None) == -1                     # queries / results missing
+        assert f(None, 3, 1, 5, 1, None) == -1                           # a table of 3 records without a pointer
+    assert L.crt_gather_plan_assemble(None, None, None, None) == -1 and L.crt_gather_plan_padded_count(None) == 0
+    assert L.crt_renderer_set_lanes(None, 2) == -1

@@ -378,3 +378,25 @@ def test_synthetic_big_identical_to_oracle(crt, env, want, monkeypatch):
     for f, _t in ora.RayStats._fields_:
         assert getattr(st, f) == getattr(ost, f), (env, f)
     assert st.shadow_rays > 0 and st.ended_depth > 0 and np.array_equal(img.view(np.uint32), oimg.view(np.uint32))
+
+
+def test_lane_count_set_through_the_abi_changes_no_bit(crt, monkeypatch):
+    """crt_renderer_set_lanes (what bench.py's one-lane roofline legs call): the same renderer traces a batch as four
+    lanes, then the next as one, then as three — the film is the one a single-lane renderer accumulates."""
+    import torch
+    monkeypatch.setenv("CRT_LANE_MIN_PATHS", "1")
+    r, _ = crt.load_usda(crt.scene_path("rectlight"), 128, 72, 4)
+    assert r.set_lanes(4) == 4
+    r.render_samples(0, 8); assert r.lanes() == 4
+    assert r.set_lanes(1) == 1
+    r.render_samples(8, 8); assert r.lanes() == 1
+    assert r.set_lanes(9) == 4 and r.set_lanes(3) == 3
+    r.render_samples(16, 7); assert r.lanes() == 3
+    torch.cuda.synchronize()
+    monkeypatch.setenv("CRT_LANES", "1")
+    ref, _ = crt.load_usda(crt.scene_path("rectlight"), 128, 72, 4)
+    ref.render_samples(0, 8); ref.render_samples(8, 8); ref.render_samples(16, 7)
+    torch.cuda.synchronize()
+    assert np.array_equal(r.image().view(np.uint32), ref.image().view(np.uint32))
+    a, b = r.stats(), ref.stats()
+    assert [getattr(a, f) for f, _t in a._fields_] == [getattr(b, f) for f, _t in b._fields_]
