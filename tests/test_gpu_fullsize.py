@@ -162,3 +162,26 @@ def test_config5_medcity_2160p(crt):
     idx = _subset(w * h, 3072, 5)
     opx, _ = o.render_pixels(idx, BATCH_4K, forward=1)
     assert np.array_equal(r.image().reshape(-1, 3)[idx].view(np.uint32), opx.view(np.uint32))
+
+
+def test_synthetic_big_7m_triangles_at_the_bench_shape(crt):
+    """`bench.py --scene synthetic:big` (LABELLED synthetic: 27 spheres at 512 x 256 quads = 7 077 888 triangles, a 1.03 GB
+    device image in a closed room under a RectLight — the out-of-cache workload whose traversal kernels are HBM-bound inside
+    the integrator): its own 1920x1080 x 128-spp batch (265.4 M paths) through the renderer's choice — one launch per stage
+    on the four-wave kernels with the large-tree arena split — on 1 024 random pixels against the oracle, whose builder
+    commits the same 7 M triangles on the CPU (per-pixel independence makes any subset exact)."""
+    import torch
+    w, h, spp = 1920, 1080, 128
+    r, desc = crt.load_usda("synthetic:big", w, h, None)
+    assert r.scene.primitive_breakdown()["triangles"] == 27 * 512 * 256 * 2 + 12 + 2
+    assert r.scene.engine_select(-4)["wide"] == 1 and r.scene.engine_select(-4)["lds_stack"] == 5
+    r.render_samples(0, spp)
+    torch.cuda.synchronize()
+    st, p = r.stats(), r.pipeline()
+    assert p["fused"] is False and p["wide"] is True
+    assert st.camera_rays == w * h * spp and st.shadow_rays > st.camera_rays and st.ended_escaped < st.camera_rays // 1000  # a closed room
+    idx = _subset(w * h, 1024, 17)
+    opx, _ = ora_world.OracleRenderer(desc, crt.usda).render_pixels(idx, spp, forward=1)
+    assert np.array_equal(r.image().reshape(-1, 3)[idx].view(np.uint32), opx.view(np.uint32))
+    del r
+    torch.cuda.empty_cache()
