@@ -194,6 +194,9 @@ constexpr uint32_t kDirectIndexMask = 0x07ffffffu;
 #ifndef CRT_POOL_NODES_DEEP
 #define CRT_POOL_NODES_DEEP 16  // with the deep stack: 16 still fit three workgroups per CU (+0.4 %); 24 do not (-33 %)
 #endif
+#ifndef CRT_WIDE_DIRECT_BUILD
+#define CRT_WIDE_DIRECT_BUILD 1  // four-wave kernel instances with the direct engine copy (WIDE = 2); CRT_WIDE=2 asks for them
+#endif
 #ifndef CRT_NOPK_BUILD
 // 1: packet-free instances of the fused kernel for images without a Tri4 packet (kNoPackets). Measured on openpbr_showcase
 // (round 4): one engine copy and 13 % fewer instructions, but 53 -> 67 spilled registers in k_path<2, true, .>: 12 294 ->
@@ -238,6 +241,7 @@ inline bool wide_split(const DevScene &s, bool renderer = false) {
 // (rounds 2 and 3 each lost a GPU box to exactly that: profiles/README.md, "The r02f abort", "The r03w fault").
 struct EngineSelect {
   bool wide = false;       // the four-workgroups-per-CU kernels (WIDE): no direct form, three LDS stack entries
+  bool wide_direct = false;  // ... their instances that hold the DIRECT engine copy only (WIDE = 2): direct-leaf images
   bool direct = false;     // the DIRECT engine copy of the three-wave kernels: reads direct child words, root test at entry
   uint32_t lds_stack = CRT_POOL_STACK;  // stack entries per ray in LDS
   uint32_t window = CRT_POOL_NODES;     // nodes staged in LDS per workgroup
@@ -249,9 +253,17 @@ struct EngineSelect {
 // CRT_ERR_UNSUPPORTED when what was asked for cannot decode the image — nothing is launched then.
 inline int select_engine(const DevScene &s, int want_wide, EngineSelect &e, bool renderer = false) {
   const bool has_direct_words = s.direct_leaves != 0;
-  if (want_wide > 0 && has_direct_words) return CRT_ERR_UNSUPPORTED;  // WIDE kernels carry no direct-leaf engine
-  e.wide = want_wide < 0 ? wide_split(s, renderer) : want_wide != 0;
-  e.direct = !e.wide && CRT_DIRECT_LEAVES != 0 && has_direct_words;
+  // the plain WIDE kernels carry no direct-leaf engine; their WIDE = 2 instances (the renderer's only) carry nothing else
+  if (want_wide == 1 && has_direct_words) return CRT_ERR_UNSUPPORTED;
+  if (want_wide == 2 && !(has_direct_words && renderer && CRT_DIRECT_LEAVES != 0 && CRT_WIDE_DIRECT_BUILD != 0)) return CRT_ERR_UNSUPPORTED;
+  // Round 4: the renderer runs DIRECT-LEAF images (instance-heavy or packet-free scenes) on the four-wave kernels too, on
+  // instances that hold the direct engine copy only — an entry the root test rejects never touches the stack, so the
+  // direct engine lives with the short LDS stack where the flat one (gauged at 1 985 against 1 977 on MedCity) did not:
+  // PointInstancedMedCity 2 234 -> 2 285 Mray/s, openpbr_showcase 13 070 -> 14 045, a 32 761-instance city 2 599 -> 2 790.
+  const bool auto_wide_direct = want_wide < 0 && renderer && has_direct_words && CRT_DIRECT_LEAVES != 0 && CRT_WIDE_DIRECT_BUILD != 0;
+  e.wide = auto_wide_direct || (want_wide < 0 ? wide_split(s, renderer) : want_wide != 0);
+  e.wide_direct = auto_wide_direct || want_wide == 2;
+  e.direct = (!e.wide || e.wide_direct) && CRT_DIRECT_LEAVES != 0 && has_direct_words;
   if (has_direct_words && !e.direct) return CRT_ERR_UNSUPPORTED;      // (a build without the direct form never writes one)
   const bool deep = s.pool_stack >= (uint32_t)CRT_POOL_STACK_DEEP;    // run_traversal's rule
   // (the wide arena's splits: the renderer's kernels, which keep no mask plane; the batched queries have one entry less)
@@ -268,7 +280,8 @@ inline int select_engine(const DevScene &s, int want_wide, EngineSelect &e, bool
 // The check every launch site makes on the EngineSelect it was handed (defence in depth: select_engine already
 // guarantees it): the instance can decode every child word of the image and keeps every cold field the image can need.
 inline bool engine_accepts(const EngineSelect &e, const DevScene &s, int kernel_cold) {
-  if (s.direct_leaves != 0 && (e.wide || !e.direct)) return false;
+  if (s.direct_leaves != 0 && ((e.wide && !e.wide_direct) || !e.direct)) return false;
+  if (e.wide_direct && s.direct_leaves == 0) return false;
   if ((kernel_cold & (int)kNoPackets) && (s.n_packets != 0 || s.direct_leaves == 0)) return false;  // a packet-free instance on packets
   return ((int)(s.cold & kColdAll) & ~kernel_cold) == 0;
 }

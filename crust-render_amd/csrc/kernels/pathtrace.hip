@@ -457,7 +457,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(Params P, PathSoA S, Counte
 // ---- extend: World::intersect (rt_world.rs:207-232) for every live path ----
 // COMPACT: the 16-byte camera path form may occur (per-stage launches only: the fused kernel never sets it, and its
 // fetch has no registers for the branch — 13 -> 27, 33 -> 97, 52 -> 122 spilled registers in the lit k_path instances).
-template <bool STATS, bool WIDE, int COLD, bool COMPACT>
+template <bool STATS, int WIDE, int COLD, bool COMPACT>
 __device__ __forceinline__ void extend_segment(const Params &P, const PathSoA &S, const HitSoA &H, Counters *C, int cur,
                                                int first, CrtTravStats *tstats, uint32_t *engine_lds) {
   __shared__ uint32_t pre[kBins + 1];
@@ -498,7 +498,7 @@ __device__ __forceinline__ void extend_segment(const Params &P, const PathSoA &S
     done++;
   };
   // the four-wave kernels keep no mask plane: every ray of the launch carries `mask` (UMASK, traverse_pool.hip.h)
-  run_traversal<false, STATS, WIDE, COLD, WIDE>(P.scene, engine_lds, 0.001f, err, st, fetch, emit, mask);
+  run_traversal<false, STATS, WIDE, COLD, WIDE != 0>(P.scene, engine_lds, 0.001f, err, st, fetch, emit, mask);
   if (err) atomicOr(&C->err, err);
   if (STATS) flush_stats(st, tstats, done);
 }
@@ -506,7 +506,7 @@ __device__ __forceinline__ void extend_segment(const Params &P, const PathSoA &S
 // COLD: the cold per-ray state the scene can need (DevScene::cold; the hit record carries no u, v, so a scene needs
 // kColdUV only for shading normals): 0 for flat-shaded static triangle scenes, kColdNormal with spheres or nested
 // instances, kColdAll otherwise and for the stats build.
-template <bool STATS, bool WIDE, int COLD>
+template <bool STATS, int WIDE, int COLD>
 __global__ __launch_bounds__(kBlock, WIDE ? 4 : CRT_EXTEND_WAVES) void k_extend(Params P, PathSoA S, HitSoA H, Counters *C, int cur,
                                                                      int first, CrtTravStats *tstats) {
   __shared__ __attribute__((aligned(16))) uint32_t engine_lds[WIDE ? kEngineLdsWide : kEngineLdsDwords];
@@ -949,7 +949,7 @@ __global__ __launch_bounds__(kBlock, WIDE ? CRT_SHADE_WIDE_WAVES : CRT_SHADE_WAV
 }
 
 // ---- shadow: World::occluded (rt_world.rs:235-237) for the queue; unoccluded requests pay out ----
-template <bool STATS, bool WIDE>
+template <bool STATS, int WIDE>
 __device__ __forceinline__ void shadow_segment(const Params &P, const PathSoA &N, const ShadowSoA &Q, Counters *C,
                                                float4 *staging, CrtTravStats *tstats, uint32_t *engine_lds) {
   const uint32_t n = ((const volatile uint32_t *)C->shadow)[blockIdx.x];
@@ -984,11 +984,11 @@ __device__ __forceinline__ void shadow_segment(const Params &P, const PathSoA &N
       N.c[tg] = v;
     }
   };
-  run_traversal<true, STATS, WIDE, (int)kColdAll, WIDE>(P.scene, engine_lds, 0.001f, err, st, fetch, emit, CRT_MASK_SHADOW);
+  run_traversal<true, STATS, WIDE, (int)kColdAll, WIDE != 0>(P.scene, engine_lds, 0.001f, err, st, fetch, emit, CRT_MASK_SHADOW);
   if (err) atomicOr(&C->err, err);
   if (STATS) flush_stats(st, tstats, done);
 }
-template <bool STATS, bool WIDE>
+template <bool STATS, int WIDE>
 __global__ __launch_bounds__(kBlock, WIDE ? 4 : CRT_SHADOW_WAVES) void k_shadow(Params P, PathSoA N, ShadowSoA Q, Counters *C,
                                                                      float4 *staging, CrtTravStats *tstats) {
   __shared__ __attribute__((aligned(16))) uint32_t engine_lds[WIDE ? kEngineLdsWide : kEngineLdsDwords];
@@ -1390,6 +1390,7 @@ struct Renderer {
     if (const int rc = plan_lane(B, p, n_samples, d_tstats)) return rc;
     float4 *staging = B.staging;
     const bool wide = !fused && this->wide;  // per-stage launches take the scene's preferred traversal kernels
+    const bool wdirect = wide && engine.wide_direct && CRT_WIDE_DIRECT_BUILD != 0;  // ... their direct-engine instances
     // camera paths as 16-byte records: per-stage launches of an UNLIT scene, pinhole camera, static scene
     // (CRT_CAM_COMPACT=0: A/B, tests)
     p.cam_compact = (CRT_CAM_COMPACT_BUILD && !fused && cam_compact_ok && P.n_lights == 0 && !(P.camera.lens_radius > 0.0f) && !P.has_motion) ? 1u : 0u;
@@ -1423,7 +1424,8 @@ struct Renderer {
     {
       EngineSelect launched = engine;
       launched.wide = wide;  // the fused kernel is a three-wave kernel whatever the scene prefers
-      launched.direct = !wide && CRT_DIRECT_LEAVES != 0 && P.scene.direct_leaves != 0;  // run_traversal picks the copy from the image
+      launched.wide_direct = wide && engine.wide_direct;
+      launched.direct = (!wide || launched.wide_direct) && CRT_DIRECT_LEAVES != 0 && P.scene.direct_leaves != 0;  // run_traversal picks the copy from the image
       const bool tail = !fused && tail_from > 0 && !d_tstats && !P.has_inf_lights;
       if (!engine_accepts(launched, P.scene, fused ? path_cold : (tail ? (ext_cold & path_cold) : ext_cold))) {
         set_error_text("render refused: the selected kernels (wide %d, cold %d / %d) cannot run this image (direct words %u, cold %u)",
@@ -1486,9 +1488,13 @@ struct Renderer {
       }
 #define CRT_EXTEND(ST, W, CO) \
   timed(0, st, [&] { hipLaunchKernelGGL((k_extend<ST, W, CO>), dim3(grid), dim3(kBlock), 0, st, p, S[cur], H, C, cur, it == 0 ? 1 : 0, d_tstats); })
-      if (d_tstats) { if (wide) CRT_EXTEND(true, true, kColdAll); else CRT_EXTEND(true, false, kColdAll); }
-      else if (wide) { if (ext_cold == 0) CRT_EXTEND(false, true, 0); else if (ext_cold == (int)kColdNormal) CRT_EXTEND(false, true, kColdNormal); else CRT_EXTEND(false, true, kColdAll); }
-      else { if (ext_cold == 0) CRT_EXTEND(false, false, 0); else if (ext_cold == (int)kColdNormal) CRT_EXTEND(false, false, kColdNormal); else CRT_EXTEND(false, false, kColdAll); }
+      // (the stats build of a direct-leaf image counts on the three-wave kernels: the counters do not depend on the engine split)
+      if (d_tstats) { if (wide && !wdirect) CRT_EXTEND(true, 1, kColdAll); else CRT_EXTEND(true, 0, kColdAll); }
+#if CRT_WIDE_DIRECT_BUILD
+      else if (wdirect) { if (ext_cold == 0) CRT_EXTEND(false, 2, 0); else if (ext_cold == (int)kColdNormal) CRT_EXTEND(false, 2, kColdNormal); else CRT_EXTEND(false, 2, kColdAll); }
+#endif
+      else if (wide) { if (ext_cold == 0) CRT_EXTEND(false, 1, 0); else if (ext_cold == (int)kColdNormal) CRT_EXTEND(false, 1, kColdNormal); else CRT_EXTEND(false, 1, kColdAll); }
+      else { if (ext_cold == 0) CRT_EXTEND(false, 0, 0); else if (ext_cold == (int)kColdNormal) CRT_EXTEND(false, 0, kColdNormal); else CRT_EXTEND(false, 0, kColdAll); }
 #undef CRT_EXTEND
 #define CRT_SHADE(M, I, W, L) \
   timed(1, st, [&] { hipLaunchKernelGGL((k_shade<M, I, W, L>), dim3(grid), dim3(kBlock), 0, st, p, S[cur], S[1 - cur], H, Q, C, cur, staging, (it == 0 ? 1 : 0) | ((int)it >= noclassify_from ? 2 : 0)); })
@@ -1503,8 +1509,11 @@ struct Renderer {
       if (P.n_lights > 0 && P.strategy != CRT_STRATEGY_BSDF) {
 #define CRT_SHADOW(ST, W) \
   timed(2, st, [&] { hipLaunchKernelGGL((k_shadow<ST, W>), dim3(grid), dim3(kBlock), 0, st, p, S[1 - cur], Q, C, staging, d_tstats ? d_tstats + 1 : nullptr); })
-        if (d_tstats) { if (wide) CRT_SHADOW(true, true); else CRT_SHADOW(true, false); }
-        else { if (wide) CRT_SHADOW(false, true); else CRT_SHADOW(false, false); }
+        if (d_tstats) { if (wide && !wdirect) CRT_SHADOW(true, 1); else CRT_SHADOW(true, 0); }
+#if CRT_WIDE_DIRECT_BUILD
+        else if (wdirect) CRT_SHADOW(false, 2);
+#endif
+        else { if (wide) CRT_SHADOW(false, 1); else CRT_SHADOW(false, 0); }
 #undef CRT_SHADOW
       }
       cur = 1 - cur;

@@ -1059,7 +1059,9 @@ static_assert(kEngineLdsWide * 4 + 512 <= 40 * 1024, "four workgroups of the wid
 // Runs the traversal for one workgroup. `lds` = kEngineLdsDwords dwords (WIDE: kEngineLdsWide), 16-byte aligned.
 // Contains a workgroup barrier: call from uniform control flow, after the shared variables the callbacks use are
 // initialised.
-template <bool ANY, bool STATS, bool WIDE, int COLD = (int)kColdAll, bool UMASK = false, class Fetch, class Emit>
+// WIDE: 0 the three-wave kernels (both engine copies, the scene's split), 1 the four-wave kernels (flat engine only),
+// 2 the four-wave kernels of direct-leaf images (DIRECT engine only; the renderer's, round 4).
+template <bool ANY, bool STATS, int WIDE, int COLD = (int)kColdAll, bool UMASK = false, class Fetch, class Emit>
 __device__ __forceinline__ void run_traversal(const DevScene &S, uint32_t *lds, float t_min, uint32_t &err, LaneStats &st,
                                               Fetch fetch, Emit emit, uint32_t umask = 0u) {
   // the split of the arena is the scene's (uniform): clamp to what the arena was sized for
@@ -1085,7 +1087,7 @@ __device__ __forceinline__ void run_traversal(const DevScene &S, uint32_t *lds, 
 #define CRT_WIDE_LEAN 1  // the four-wave kernels fetch a packet in stages (LEAN); 0: whole, as the three-wave ones (A/B)
 #endif
 #define CRT_ENGINE(D) traverse_pool<ANY, STATS, CRT_POOL_ROWS, D, (WIDE && CRT_WIDE_LEAN != 0), COLD, UMASK>(S, wave_lds, t_min, umask, lds_nodes, n_lds, n_lds_pk, pstack, err, st, fetch, emit)
-  if ((COLD & (int)kNoPackets) != 0) CRT_ENGINE(true);  // a packet-free image: the direct engine is the only copy (select_engine)
+  if ((COLD & (int)kNoPackets) != 0 || WIDE == 2) CRT_ENGINE(true);  // one copy, the direct engine (select_engine)
   else if (CRT_DIRECT_LEAVES != 0 && !WIDE && S.direct_leaves != 0) CRT_ENGINE(true);
   else CRT_ENGINE(false);
 #undef CRT_ENGINE

@@ -189,7 +189,7 @@ Knobs read_knobs() {
   if (num("CRT_COLD", v)) k.cold = (uint32_t)v & kColdAll;
   if (num("CRT_INST_ORDER", v)) k.inst_order = v != 0;
   if (num("CRT_HOT_PACKETS", v)) k.hot_packets = v != 0;
-  if (num("CRT_WIDE", v)) k.wide = v != 0;
+  if (num("CRT_WIDE", v)) k.wide = v == 2 ? 2 : (v != 0);  // 2: the four-wave kernels' direct-engine instances (direct-leaf images)
   if (num("CRT_MAT_DEDUP", v)) k.mat_dedup = v != 0;
   if (num("CRT_PARTITION", v)) k.partition = v != 0;
   if (num("CRT_SIMPLE", v)) k.simple = v != 0;
@@ -665,11 +665,12 @@ int scene_engine_select(const Scene &scene, int want_wide, uint32_t out[8]) {
                    (int)e.direct, n_direct, need_cold, e.ext_cold, e.path_cold);
     return CRT_ERR_BAD_ARG;
   };
-  if (n_direct && (e.wide || !e.direct)) return fail("the image holds direct child words the selected instance cannot read");
+  if (n_direct && ((e.wide && !e.wide_direct) || !e.direct)) return fail("the image holds direct child words the selected instance cannot read");
+  if (e.wide_direct && !v.direct_leaves) return fail("the direct-engine instances of the four-wave kernels selected for an image without direct words");
   if (n_direct && !v.direct_leaves) return fail("direct words in an image whose view says there are none");
   if ((need_cold & ~(uint32_t)e.ext_cold) || (need_cold & ~(uint32_t)e.path_cold)) return fail("the image needs cold state the selected kernels do not keep");
   if (!engine_accepts(e, v, e.ext_cold) || !engine_accepts(e, v, e.path_cold)) return fail("engine_accepts disagrees with select_engine");
-  out[0] = e.wide; out[1] = e.direct; out[2] = e.lds_stack; out[3] = e.window;
+  out[0] = e.wide ? (e.wide_direct ? 2u : 1u) : 0u; out[1] = e.direct; out[2] = e.lds_stack; out[3] = e.window;
   out[4] = (uint32_t)e.ext_cold; out[5] = (uint32_t)e.path_cold; out[6] = n_direct; out[7] = v.cold;
   return CRT_OK;
 }

@@ -141,7 +141,8 @@ int crt_scene_image_check(CrtScene *s, uint64_t out[8]);
  * exactly what a batched query's launch would pick in this process (the CRT_WIDE A/B request included, which falls back
  * where refused), -3 = what the renderer's launches would (they differ on large flat trees), -4 = the renderer's preference;
  * CRT_ERR_UNSUPPORTED when what was asked for cannot decode the image (nothing would be launched), CRT_ERR_BAD_ARG +
- * crt_last_error on a broken invariant. out: four-wave kernels | direct-leaf engine copy | LDS stack entries per ray |
+ * crt_last_error on a broken invariant. out: four-wave kernels (1; 2 = their direct-engine instances, which the renderer
+ * runs direct-leaf images on) | direct-leaf engine copy | LDS stack entries per ray |
  * nodes staged in LDS | cold mask of the per-stage closest-hit kernel | of the fused kernel | direct words in the image |
  * cold mask the image needs. (No reference counterpart: the reference has one scalar traversal, bvh.rs:441-509.) */
 int crt_scene_engine_select(CrtScene *s, int want_wide, uint32_t out[8]);

@@ -263,9 +263,15 @@ def test_every_knob_combination_selects_an_engine_that_can_decode_the_image(crt,
             monkeypatch.delenv(k, raising=False) if v is None else monkeypatch.setenv(k, v)
         env = dict(zip(_ENGINE_KNOBS, combo))
         for name, scene in built.items():
-            scene.engine_select(-3)        # the renderer's launches (they differ from the queries' on large flat trees)
-            sel = scene.engine_select(-2)  # raises on a selection the image census contradicts
             img = scene.image_check()
+            rsel = scene.engine_select(-3)  # the renderer's launches: large flat trees and direct-leaf images differ from the queries'
+            if img["direct_leaves"] and env["CRT_WIDE"] != "0":
+                assert rsel["wide"] == 2 and rsel["direct"] == 1, (name, env)  # four-wave kernels, direct-engine instances
+            elif env["CRT_WIDE"] == "0":
+                assert rsel["wide"] == 0, (name, env)
+            else:
+                assert rsel["wide"] in (0, 1) and rsel["direct_words"] == 0, (name, env)
+            sel = scene.engine_select(-2)  # raises on a selection the image census contradicts
             words = img["leaf_words_direct_index"] + img["leaf_words_direct_instance"]
             assert sel["direct_words"] == words, (name, env)
             if words or img["direct_leaves"]:

@@ -187,12 +187,9 @@ def test_the_three_pipelines_agree(crt, tmp_path, scene, w, h, depth):
         "np.save(sys.argv[1], r.image()); print(st.closest_hit, st.shadow_rays, st.vertices, st.rr_killed, int(p1['fused']), int(p1['wide']), int(p2['fused']))\n"
         % (ROOT, scene, w, h, depth))
     outs = []
-    # the four-wave kernels are built without the direct-leaf form and CRT_WIDE=1 cannot force them onto a scene that has
-    # direct leaf words (packet-free: the showcase's spheres): there "stage4" is the three-wave per-stage pipeline again
-    # (crt_scene_engine_select says which: what CRT_WIDE=1 may be honoured on, host-only)
-    probe, _ = crt.usda.build_world(crt.usda.load(crt.scene_path(scene), w, h), crt, crt.default_material)[0], None
-    wide = 0 if probe.image_check()["direct_leaves"] else 1
-    assert wide == (0 if scene == "openpbr_showcase" else 1)
+    # every scene's renderer has four-wave traversal kernels to run: flat trees the plain ones, direct-leaf images
+    # (openpbr_showcase: packet-free) their direct-engine instances — CRT_WIDE=1 on such an image falls back to that choice
+    wide = 1
     for tag, env, want in (("fused", dict(CRT_FUSED="1"), (1, 0, 1)), ("stage3", dict(CRT_FUSED="0", CRT_WIDE="0"), (0, 0, 0)),
                            ("stage4", dict(CRT_FUSED="0", CRT_WIDE="1"), (0, wide, 0)),
                            # the batch decides: 5 spp of every pixel reach the threshold, 3 do not
