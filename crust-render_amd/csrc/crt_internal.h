@@ -183,7 +183,8 @@ constexpr uint32_t kDirectIndexMask = 0x07ffffffu;
 #define CRT_POOL_NODES_WIDE 26  // the four-workgroups-per-CU kernels (small flat scenes)
 #endif
 #ifndef CRT_POOL_NODES_WIDE_DEEP
-#define CRT_POOL_NODES_WIDE_DEEP 8  // ... of the four-wave kernels on a large tree (they trade the window for stack entries)
+#define CRT_POOL_NODES_WIDE_DEEP 12  // ... of the four-wave kernels on a large tree or an instance-heavy scene (they trade the window for stack
+                                     // entries; 12 is what the 40 KB arena has left beside five entries: MedCity's root + its 8 prototype roots fit, +1.3 % over 8)
 #endif
 #ifndef CRT_DIRECT_INST
 #define CRT_DIRECT_INST 1  // 0: the direct-instance form is neither written nor understood (A/B builds)

@@ -1046,7 +1046,7 @@ constexpr int kPoolNodesWide = CRT_POOL_NODES_WIDE;  // crt_internal.h
 // 2466, the 7 M-triangle scene 3172 / 3307; at 6 + 72 on three waves: stress 2249 — the depth of the LDS part of the
 // stack is what large trees pay for, profiles/README.md.)
 #ifndef CRT_POOL_NODES_WIDE_DEEP
-#define CRT_POOL_NODES_WIDE_DEEP 8
+#define CRT_POOL_NODES_WIDE_DEEP 12
 #endif
 __host__ __device__ constexpr int wide_stack(bool deep_tree, bool umask) { return kPoolStackWide + (deep_tree ? 1 : 0) + (umask ? 1 : 0); }
 __host__ __device__ constexpr int wide_nodes(bool deep_tree) { return deep_tree ? CRT_POOL_NODES_WIDE_DEEP : kPoolNodesWide; }

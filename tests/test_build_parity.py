@@ -280,7 +280,7 @@ def test_every_knob_combination_selects_an_engine_that_can_decode_the_image(crt,
                     scene.engine_select(1)
                 assert refused.value.code == -5
             if sel["wide"]:
-                assert words == 0 and (sel["lds_stack"], sel["window"]) in ((4, 26), (5, 8)), (name, env)
+                assert words == 0 and (sel["lds_stack"], sel["window"]) in ((4, 26), (5, 12)), (name, env)
             else:
                 assert sel["lds_stack"] in (6, 10) and sel["window"] == (16 if sel["lds_stack"] == 10 else 72), (name, env)
             assert sel["cold"] & ~sel["ext_cold"] == 0 and sel["cold"] & ~sel["path_cold"] == 0, (name, env)

@@ -358,13 +358,13 @@ def test_synthetic_big_identical_to_oracle(crt, env, want, monkeypatch):
     """The labelled synthetic out-of-cache workload (synthetic.big: 27 tessellated spheres in a closed room under a rect
     light; here 96 x 48 quads per sphere = 248 832 triangles, the bench runs 512 x 256 = 7.08 M): a large flat tree. The
     renderer's own choice for it — one launch per stage on the four-wave kernels with their large-tree split (five stack
-    entries, eight-node window, no mask plane; here forced onto a small batch) —, the three-wave per-stage kernels on the
+    entries, twelve-node window, no mask plane; here forced onto a small batch) —, the three-wave per-stage kernels on the
     deep split, and the fused kernel: image and all eight counters identical to the oracle."""
     import torch
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     r, desc = crt.load_usda("synthetic:big:96", 96, 54, 6)
-    assert r.scene.engine_select(-4) == dict(r.scene.engine_select(-4), wide=1, direct=0, lds_stack=5, window=8)  # the renderer's preference
+    assert r.scene.engine_select(-4) == dict(r.scene.engine_select(-4), wide=1, direct=0, lds_stack=5, window=12)  # the renderer's preference
     assert r.scene.engine_select(-1)["wide"] == 0 and r.scene.engine_select(-1)["lds_stack"] == 10              # the batched queries'
     r.render_samples(0, 4)
     torch.cuda.synchronize()
