@@ -216,7 +216,7 @@ constexpr uint32_t kDirectIndexMask = 0x07ffffffu;
 // ... and only images WITHOUT direct child words: the four-wave kernels are built without the direct-leaf engine copy
 // (run_traversal), so a direct word would be read as a leaf index (the round-3 fault, profiles/README.md).
 // Round 4: LARGE flat trees too, in the renderer — its four-wave kernels keep no mask plane and split their arena by tree
-// (five stack entries + an eight-node window; traverse_pool.hip.h): the reference's stress scene 2538 -> 2738 Mray/s
+// (five stack entries + a twelve-node window; traverse_pool.hip.h): the reference's stress scene 2538 -> 2738 Mray/s
 // (+7.9 %), the 7 M-triangle synthetic scene +0.7 %. The batched queries (one stack entry less: per-ray masks) keep the
 // three-wave kernels on those trees, as do the mid-size ones (1 024 < nodes <= 2 048: the flat 6 + 72 split).
 inline bool wide_split(const DevScene &s, bool renderer = false) {

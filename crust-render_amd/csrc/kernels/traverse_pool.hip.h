@@ -1039,12 +1039,14 @@ constexpr int kEngineLdsDwords = kEngineLdsFlat > kEngineLdsDeep ? kEngineLdsFla
 // (crt_internal.h, wide_split).
 constexpr int kPoolStackWide = CRT_POOL_STACK_WIDE;
 constexpr int kPoolNodesWide = CRT_POOL_NODES_WIDE;  // crt_internal.h
-// Round 4: the wide arena's split follows the tree too. A large tree (DevScene::pool_stack = the deep split's, scene.cpp)
-// trades the node window — 26 of its 100 000 nodes — for stack entries: 4 + 8 instead of 3 + 26; and the renderer's
-// kernels, whose rays all carry one mask (UMASK: no mask plane), have one more entry in the same bytes: 4 + 26 for small
-// trees, 5 + 8 for large ones. (Four-wave kernels at 3 + 26 against three-wave ones at 10 + 16, Mray/s: stress 2521 /
-// 2466, the 7 M-triangle scene 3172 / 3307; at 6 + 72 on three waves: stress 2249 — the depth of the LDS part of the
-// stack is what large trees pay for, profiles/README.md.)
+// Round 4: the wide arena's split follows the tree too. A large tree or an instance-heavy scene (DevScene::pool_stack = the
+// deep split's, scene.cpp) trades the node window — 26 of its tens of thousands of nodes — for stack entries: 4 + 12 instead
+// of 3 + 26; and the renderer's kernels, whose rays all carry one mask (UMASK: no mask plane), have one more entry in the
+// same bytes: 4 + 26 for small trees, 5 + 12 for large ones — 12 nodes being what the 40 KB arena has left beside five
+// entries (measured at 5 + 8 first; 12: PointInstancedMedCity +1.3 %, its root and eight prototype roots then all sit in
+// the window). (Four-wave kernels at 3 + 26 against three-wave ones at 10 + 16, Mray/s: stress 2521 / 2466, the
+// 7 M-triangle scene 3172 / 3307; at 6 + 72 on three waves: stress 2249 — the depth of the LDS part of the stack is what
+// large trees pay for, profiles/README.md.)
 #ifndef CRT_POOL_NODES_WIDE_DEEP
 #define CRT_POOL_NODES_WIDE_DEEP 12
 #endif
