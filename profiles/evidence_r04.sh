@@ -20,6 +20,10 @@ case $PART in
   rm -f profiles/r04_pmc_bench.json
   bash profiles/pmc_r04.sh $T cb stress
   ;;
+1p) # the PMC passes of part 1 alone (after a change that leaves the tests' outcome as it was, e.g. comments in the kernel sources)
+  rm -f profiles/r04_pmc_bench.json
+  bash profiles/pmc_r04.sh $T cb stress
+  ;;
 2)
   bash profiles/pmc_r04.sh $T big veach showcase
   python profiles/pmc_per_launch.py ${T}big k_extend k_shadow > gpurun_out/${T}_pmc_per_launch_big.json
