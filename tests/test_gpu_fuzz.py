@@ -14,9 +14,10 @@ f32 = np.float32
 import os
 
 _EXTRA = int(os.environ.get("CRT_FUZZ_EXTRA", "0"))  # CRT_FUZZ_EXTRA=N: N more seeds per test (soak runs)
+_BASE = int(os.environ.get("CRT_FUZZ_BASE", "0"))  # CRT_FUZZ_BASE=B: the extra seeds start B later (a soak run on seeds no earlier one saw)
 
 
-@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16, 17, 18] + list(range(1000, 1000 + _EXTRA)))
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16, 17, 18] + list(range(1000 + _BASE, 1000 + _BASE + _EXTRA)))
 def test_random_scene_matches_oracle_bitwise(crt, seed):
     import torch
     recipe = fuzz_scenes.recipe(seed)
@@ -52,7 +53,7 @@ def test_random_scene_matches_oracle_bitwise(crt, seed):
         assert np.array_equal(got_occ.cpu().numpy().astype(np.uint8), occ)
 
 
-@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106, 107, 108, 109, 110] + list(range(2000, 2000 + _EXTRA)))
+@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106, 107, 108, 109, 110] + list(range(2000 + _BASE, 2000 + _BASE + _EXTRA)))
 def test_random_world_renders_identically(crt, seed):
     """Random OpenPBR materials (every lobe, interior media, thin walls, dispersion, thin film, emission), sphere and
     rect lights, all four sampling strategies, both filters, thin-lens cameras: image and counters identical."""
