@@ -53,6 +53,19 @@ def test_random_scene_matches_oracle_bitwise(crt, seed):
         assert np.array_equal(got_occ.cpu().numpy().astype(np.uint8), occ)
 
 
+_CENSUS = {}  # engine instance the renderer's selection names (0 three-wave, 1 four-wave flat copy, 2 four-wave direct copy) -> worlds
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _engine_census():
+    """CRT_FUZZ_CENSUS=path: which engine instances a soak run's worlds ran on, written when the module is done."""
+    yield
+    path = os.environ.get("CRT_FUZZ_CENSUS")
+    if path and _CENSUS:
+        with open(path, "a") as f:
+            f.write("worlds by engine instance (0 three-wave, 1 four-wave flat, 2 four-wave direct): %s\n" % dict(sorted(_CENSUS.items())))
+
+
 @pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106, 107, 108, 109, 110] + list(range(2000 + _BASE, 2000 + _BASE + _EXTRA)))
 def test_random_world_renders_identically(crt, seed):
     """Random OpenPBR materials (every lobe, interior media, thin walls, dispersion, thin film, emission), sphere and
@@ -68,6 +81,8 @@ def test_random_world_renders_identically(crt, seed):
     r.render_samples(0, 6)
     torch.cuda.synchronize()
     img, st = r.image(), r.stats()
+    w = scene.engine_select(-3)["wide"]  # the renderer's selection in this process (environment included)
+    _CENSUS[w] = _CENSUS.get(w, 0) + 1
     oimg, ost = ora_world.OracleRenderer(desc, crt.usda).render(6, forward=1)
     for f, _t in ora.RayStats._fields_:
         assert getattr(st, f) == getattr(ost, f), (seed, f, getattr(st, f), getattr(ost, f))
