@@ -30,12 +30,63 @@ float ora_bounce_weight(int s, float bounce_pdf, float light_pdf) { /* tracer.rs
 }
 static int samples_lights(int s) { return s != ORA_STRATEGY_BSDF; } /* tracer.rs:79-81 */
 
+/* Seam hooks (ora_pt.h): every call the integrator makes across the kernel seam and the Material / Light traits goes
+ * through one of the s_* functions below. */
+static OraSeamHooks g_hooks;
+void ora_set_seam_hooks(const OraSeamHooks *hooks) {
+  if (hooks) g_hooks = *hooks; else memset(&g_hooks, 0, sizeof g_hooks);
+}
+static void put3(float *d, v3 a) { d[0] = a.x; d[1] = a.y; d[2] = a.z; }
+static int s_intersect(const OraRenderJob *job, const OraRay *ray, float t_min, float t_max, OraRayHit *h) {
+  return g_hooks.intersect ? g_hooks.intersect(g_hooks.ctx, ray, t_min, t_max, h) : ora_intersect(job->scene, ray, t_min, t_max, h);
+}
+static int s_occluded(const OraRenderJob *job, const OraRay *ray, float t_min, float t_max) {
+  return g_hooks.occluded ? g_hooks.occluded(g_hooks.ctx, ray, t_min, t_max) : ora_occluded(job->scene, ray, t_min, t_max);
+}
+static int s_mat_scatter(const OraRenderJob *job, const OraMaterial *m, v3 ray_dir, const OraHitRecord *rec, OraSampler dom,
+                         OraScatter *out) {
+  if (!g_hooks.mat_scatter) return ora_mat_scatter(m, ray_dir, rec, dom, out);
+  float d[3]; put3(d, ray_dir);
+  return g_hooks.mat_scatter(g_hooks.ctx, (uint32_t)(m - job->materials), d, rec, dom.pattern, dom.index, out);
+}
+static int s_mat_eval(const OraRenderJob *job, const OraMaterial *m, v3 ray_dir, const OraHitRecord *rec, v3 wi, v3 *value,
+                      float *pdf) {
+  if (!g_hooks.mat_eval) return ora_mat_eval(m, ray_dir, rec, wi, value, pdf);
+  float d[3], w[3], val[3] = {0.0f, 0.0f, 0.0f}; put3(d, ray_dir); put3(w, wi);
+  int some = g_hooks.mat_eval(g_hooks.ctx, (uint32_t)(m - job->materials), d, rec, w, val, pdf);
+  *value = v3_new(val[0], val[1], val[2]);
+  return some;
+}
+static v3 s_mat_emitted(const OraRenderJob *job, const OraMaterial *m, float cos_o) {
+  if (!g_hooks.mat_emitted) return ora_mat_emitted_directional(m, cos_o);
+  float rgb[3] = {0.0f, 0.0f, 0.0f};
+  g_hooks.mat_emitted(g_hooks.ctx, (uint32_t)(m - job->materials), cos_o, rgb);
+  return v3_new(rgb[0], rgb[1], rgb[2]);
+}
+static int s_light_sample(const OraRenderJob *job, const OraLight *l, v3 from, float u, float v, OraLightSample *out) {
+  if (!g_hooks.light_sample) return ora_light_sample_li(l, from, u, v, out);
+  float f[3]; put3(f, from);
+  return g_hooks.light_sample(g_hooks.ctx, (uint32_t)(l - job->lights), f, u, v, out);
+}
+static float s_light_pdf(const OraRenderJob *job, const OraLight *l, v3 from, v3 point) {
+  if (!g_hooks.light_pdf) return ora_light_pdf_at_point(l, from, point);
+  float f[3], p[3]; put3(f, from); put3(p, point);
+  return g_hooks.light_pdf(g_hooks.ctx, (uint32_t)(l - job->lights), f, p);
+}
+static int s_light_escaped(const OraRenderJob *job, const OraLight *l, v3 direction, v3 *emitted, float *pdf) {
+  if (!g_hooks.light_escaped) return ora_light_escaped(l, direction, emitted, pdf);
+  float d[3], e[3] = {0.0f, 0.0f, 0.0f}; put3(d, direction);
+  int some = g_hooks.light_escaped(g_hooks.ctx, (uint32_t)(l - job->lights), d, e, pdf);
+  *emitted = v3_new(e[0], e[1], e[2]);
+  return some;
+}
+
 /* rt_world.rs:191-196 */
 typedef struct { OraHitRecord rec; const OraMaterial *mat; uint32_t geom_id, prim_id; } WorldHit;
 
 static int world_intersect(const OraRenderJob *job, const OraRay *ray, float t_min, float t_max, WorldHit *out) {
   OraRayHit h; /* rt_world.rs:207-232 */
-  if (!ora_intersect(job->scene, ray, t_min, t_max, &h)) return 0;
+  if (!s_intersect(job, ray, t_min, t_max, &h)) return 0;
   out->rec.p = v3_add(ray->origin, v3_scale(ray->dir, h.t));
   out->rec.normal = h.normal;
   out->rec.t = h.t;
@@ -60,10 +111,10 @@ static const OraLight *find_by_geom(const OraRenderJob *job, uint32_t geom_id) {
 
 static float bounce_emission_weight(const OraRenderJob *job, const PrevBounce *p, const WorldHit *hit) { /* tracer.rs:930-953 */
   v3 val; float pdf;
-  if (p->delta || !ora_mat_eval(p->mat, p->ray_dir, &p->rec, p->dir, &val, &pdf)) return 1.0f;
+  if (p->delta || !s_mat_eval(job, p->mat, p->ray_dir, &p->rec, p->dir, &val, &pdf)) return 1.0f;
   const OraLight *light = find_by_geom(job, hit->geom_id);
   if (!light) return 1.0f;
-  float light_pdf = ora_max(ora_light_pdf_at_point(light, p->rec.p, hit->rec.p) / (float)job->n_lights, 1e-6f);
+  float light_pdf = ora_max(s_light_pdf(job, light, p->rec.p, hit->rec.p) / (float)job->n_lights, 1e-6f);
   return ora_bounce_weight(job->strategy, p->pdf, light_pdf);
 }
 
@@ -99,7 +150,7 @@ static v3 trace_path(const OraRenderJob *job, const OraRay *r, OraSampler sample
         WorldHit hit;
         if (world_intersect(job, &ray, 0.001f, ORA_INF, &hit)) {
           float cos_o = ora_abs(v3_dot(v3_normalize(ray.dir), hit.rec.normal));
-          v3 emitted = ora_mat_emitted_directional(hit.mat, cos_o);
+          v3 emitted = s_mat_emitted(job, hit.mat, cos_o);
           if (v3_len2(emitted) > 0.0f) {
             if (has_med) emitted = v3_mul(emitted, ora_medium_transmittance(&med, hit.rec.t)); /* tracer.rs:1134-1136 */
             float w = bounce_emission_weight(job, &prev, &hit);
@@ -169,7 +220,7 @@ static v3 trace_path(const OraRenderJob *job, const OraRay *r, OraSampler sample
         float n_lights = (float)job->n_lights;
         for (uint32_t k = 0; k < job->n_lights; k++) {
           v3 emitted; float pdf;
-          if (!ora_light_escaped(&job->lights[k], unit_direction, &emitted, &pdf)) continue;
+          if (!s_light_escaped(job, &job->lights[k], unit_direction, &emitted, &pdf)) continue;
           covered = 1;
           float weight = 1.0f;
           if (competing && samples_lights(job->strategy)) {
@@ -201,7 +252,7 @@ static v3 trace_path(const OraRenderJob *job, const OraRay *r, OraSampler sample
 
     /* tracer.rs:1369-1381 */
     float cos_o = ora_abs(v3_dot(v3_normalize(ray.dir), rec.normal));
-    v3 emitted = ora_mat_emitted_directional(mat, cos_o);
+    v3 emitted = s_mat_emitted(job, mat, cos_o);
     v3 emit_here = v3_splat(0.0f);
     if (prev.valid) {
       if (v3_len2(emitted) > 0.0f) {
@@ -223,16 +274,16 @@ static v3 trace_path(const OraRenderJob *job, const OraRay *r, OraSampler sample
       if (li > job->n_lights - 1) li = job->n_lights - 1;
       const OraLight *light = &job->lights[li];
       OraLightSample ls;
-      if (ora_light_sample_li(light, rec.p, nee_s[1], nee_s[2], &ls)) {
+      if (s_light_sample(job, light, rec.p, nee_s[1], nee_s[2], &ls)) {
         float n_lights = (float)job->n_lights;
         OraRay shadow_ray = {rec.p, ls.direction, ray.time, ORA_MASK_SHADOW};
         stats->shadow_rays++; /* tracer.rs:1026 */
-        int occluded = ora_occluded(job->scene, &shadow_ray, 0.001f, ls.distance - 0.001f);
+        int occluded = s_occluded(job, &shadow_ray, 0.001f, ls.distance - 0.001f);
         if (!occluded) {
           float cosine = ora_abs(v3_dot(rec.normal, ls.direction));
           float light_pdf = ora_max(ls.pdf / n_lights, 1e-6f);
           v3 brdf_value; float brdf_pdf;
-          if (ora_mat_eval(mat, ray.dir, &rec, ls.direction, &brdf_value, &brdf_pdf)) {
+          if (s_mat_eval(job, mat, ray.dir, &rec, ls.direction, &brdf_value, &brdf_pdf)) {
             float weight = ora_light_weight(job->strategy, light_pdf, brdf_pdf);
             v3 c = v3_scale(v3_mul(ls.radiance, brdf_value), cosine);
             c = v3_mul(c, one); /* shadow_tr == ONE */
@@ -253,7 +304,7 @@ static v3 trace_path(const OraRenderJob *job, const OraRay *r, OraSampler sample
 
     /* === 2. bounce (tracer.rs:1459-1523) === */
     OraScatter sample;
-    if (ora_mat_scatter(mat, ray.dir, &rec, ora_new_domain(v, K_BSDF), &sample)) {
+    if (s_mat_scatter(job, mat, ray.dir, &rec, ora_new_domain(v, K_BSDF), &sample)) {
       v3 dir = v3_normalize(sample.dir);
       float cosine = sample.delta ? 1.0f : ora_abs(v3_dot(rec.normal, dir));
       v3 factor = v3_divs(v3_scale(sample.value, cosine), sample.pdf);

@@ -51,6 +51,27 @@ uint32_t ora_render_pixel(const OraRenderJob *job, uint32_t i, uint32_t j, float
 void ora_render_sample(const OraRenderJob *job, uint32_t i, uint32_t j, uint32_t sample, float rgb[3],
                        OraRayStats *stats);
 
+/* Seam hooks (tests only): the integrator above calls the kernel seam (World::intersect / occluded, rt_world.rs:207-237)
+ * and the Material / Light trait methods (material.rs:26-116, light.rs:120-151) through these when they are set — so a
+ * test can run THIS per-pixel integrator, unmodified, on somebody else's implementation of the seam (the device's, through
+ * libcrt_amd's C ABI) and compare images bit for bit. NULL members fall through to the oracle's own functions. One global
+ * table, not thread-safe: render with one thread while hooks are set. Materials and lights are named by their index in
+ * the job's tables (materials: by geom_id, rt_world.rs:229). */
+typedef struct OraSeamHooks {
+  void *ctx;
+  int (*intersect)(void *ctx, const OraRay *ray, float t_min, float t_max, OraRayHit *out);
+  int (*occluded)(void *ctx, const OraRay *ray, float t_min, float t_max);
+  int (*mat_scatter)(void *ctx, uint32_t material, const float *ray_dir, const OraHitRecord *rec, uint32_t dom_pattern,
+                     uint32_t dom_index, OraScatter *out);
+  int (*mat_eval)(void *ctx, uint32_t material, const float *ray_dir, const OraHitRecord *rec, const float *wi, float *value,
+                  float *pdf);
+  void (*mat_emitted)(void *ctx, uint32_t material, float cos_theta_o, float *rgb);
+  int (*light_sample)(void *ctx, uint32_t light, const float *from, float u, float v, OraLightSample *out);
+  float (*light_pdf)(void *ctx, uint32_t light, const float *from, const float *point);
+  int (*light_escaped)(void *ctx, uint32_t light, const float *direction, float *radiance, float *pdf);
+} OraSeamHooks;
+void ora_set_seam_hooks(const OraSeamHooks *hooks); /* NULL: the oracle's own functions again */
+
 float ora_light_weight(int strategy, float light_pdf, float bounce_pdf);  /* tracer.rs:85-92 */
 float ora_bounce_weight(int strategy, float bounce_pdf, float light_pdf); /* tracer.rs:97-104 */
 

@@ -152,6 +152,29 @@ class RenderJob(C.Structure):
                 ("forward", C.c_int32)]
 
 
+_fpp, _u32 = C.POINTER(C.c_float), C.c_uint32
+
+
+class SeamHooks(C.Structure):
+    """OraSeamHooks (ora_pt.h): the integrator's calls across the kernel seam and the Material / Light traits."""
+    INTERSECT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(Ray), C.c_float, C.c_float, C.POINTER(RayHit))
+    OCCLUDED = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(Ray), C.c_float, C.c_float)
+    MAT_SCATTER = C.CFUNCTYPE(C.c_int, C.c_void_p, _u32, _fpp, C.POINTER(HitRecord), _u32, _u32, C.POINTER(Scatter))
+    MAT_EVAL = C.CFUNCTYPE(C.c_int, C.c_void_p, _u32, _fpp, C.POINTER(HitRecord), _fpp, _fpp, _fpp)
+    MAT_EMITTED = C.CFUNCTYPE(None, C.c_void_p, _u32, C.c_float, _fpp)
+    LIGHT_SAMPLE = C.CFUNCTYPE(C.c_int, C.c_void_p, _u32, _fpp, C.c_float, C.c_float, C.POINTER(LightSample))
+    LIGHT_PDF = C.CFUNCTYPE(C.c_float, C.c_void_p, _u32, _fpp, _fpp)
+    LIGHT_ESCAPED = C.CFUNCTYPE(C.c_int, C.c_void_p, _u32, _fpp, _fpp, _fpp)
+    _fields_ = [("ctx", C.c_void_p), ("intersect", INTERSECT), ("occluded", OCCLUDED), ("mat_scatter", MAT_SCATTER),
+                ("mat_eval", MAT_EVAL), ("mat_emitted", MAT_EMITTED), ("light_sample", LIGHT_SAMPLE),
+                ("light_pdf", LIGHT_PDF), ("light_escaped", LIGHT_ESCAPED)]
+
+
+def set_seam_hooks(hooks):
+    """hooks: a SeamHooks (keep it alive while set) or None."""
+    lib().ora_set_seam_hooks(C.byref(hooks) if hooks is not None else None)
+
+
 _lib = None
 
 
@@ -300,6 +323,8 @@ def lib():
     L.ora_render.argtypes = [C.POINTER(RenderJob), fp, C.POINTER(RayStats), C.c_int]
     L.ora_render_pixels.argtypes = [C.POINTER(RenderJob), C.POINTER(C.c_uint32), C.c_size_t, fp, C.POINTER(RayStats), C.c_int]
     L.ora_render_serial_trav.argtypes = [C.POINTER(RenderJob), fp, C.POINTER(RayStats), C.POINTER(TravStats), C.POINTER(TravStats)]
+    L.ora_set_seam_hooks.argtypes = [C.c_void_p]
+    L.ora_set_seam_hooks.restype = None
     L.ora_render_pixel.restype = C.c_uint32
     L.ora_render_pixel.argtypes = [C.POINTER(RenderJob), C.c_uint32, C.c_uint32, fp, C.POINTER(RayStats)]
     L.ora_render_sample.argtypes = [C.POINTER(RenderJob), C.c_uint32, C.c_uint32, C.c_uint32, fp,
