@@ -212,13 +212,16 @@ class SeamHost:
 
 
 # scene, width, height, spp, depth, the seam functions the scene must have exercised
-CASES = [("cornellbox", 20, 20, 2, 6, ("intersect", "scatter", "emitted")),
-         ("veach_mis", 24, 14, 2, 6, ("intersect", "occluded", "scatter", "eval", "emitted", "sample_li", "pdf_at_point")),
-         ("openpbr_showcase", 24, 14, 2, 12, ("intersect", "occluded", "scatter", "eval", "emitted", "sample_li")),
-         ("sun_sky", 24, 14, 2, 6, ("intersect", "occluded", "scatter", "eval", "sample_li", "escaped")),
-         ("rectlight", 24, 14, 2, 4, ("intersect", "occluded", "scatter", "eval", "sample_li", "pdf_at_point")),
-         ("motionblur", 24, 14, 2, 4, ("intersect", "scatter")),
-         ("instancing", 24, 14, 2, 6, ("intersect", "scatter"))]
+CASES = [("cornellbox", 32, 32, 4, 8, ("intersect", "scatter", "emitted")),
+         ("veach_mis", 40, 24, 4, 8, ("intersect", "occluded", "scatter", "eval", "emitted", "sample_li", "pdf_at_point")),
+         ("openpbr_showcase", 40, 24, 4, 12, ("intersect", "occluded", "scatter", "eval", "emitted", "sample_li")),
+         ("sun_sky", 40, 24, 4, 8, ("intersect", "occluded", "scatter", "eval", "sample_li", "escaped")),
+         ("domelight", 40, 24, 2, 8, ("intersect", "occluded", "scatter", "eval", "sample_li", "escaped")),
+         ("rectlight", 40, 24, 4, 4, ("intersect", "occluded", "scatter", "eval", "sample_li", "pdf_at_point")),
+         ("light_visibility", 40, 24, 2, 4, ("intersect", "occluded", "scatter", "eval", "sample_li")),
+         ("motionblur", 40, 24, 4, 4, ("intersect", "scatter")),
+         ("instancing", 40, 24, 2, 8, ("intersect", "scatter")),
+         ("nested_instancing", 40, 24, 2, 8, ("intersect", "scatter"))]
 
 
 def check_against_own(name, host, o, spp, forward, must_call):
