@@ -7,7 +7,7 @@ set -e
 R=$(cd "$(dirname "$0")/.." && pwd); T=${TMPDIR:-/tmp}/crt_asan; mkdir -p $T; cd $R/crust-render_amd/csrc
 F="--offload-arch=gfx950 -g -fPIC -std=c++17 -ffp-contract=off -fno-fast-math -I../../include -fsanitize=address,undefined -fno-gpu-sanitize -fno-omit-frame-pointer"
 for f in bvh_build scene capi; do /opt/rocm/bin/hipcc $F -O1 -x hip -c $f.cpp -o $T/$f.o 2>/dev/null & done
-for f in traverse pathtrace; do /opt/rocm/bin/hipcc $F -O2 -fno-slp-vectorize -c kernels/$f.hip -o $T/$f.o 2>/dev/null & done
+for f in traverse pathtrace shade_seam gather; do /opt/rocm/bin/hipcc $F -O2 -fno-slp-vectorize -c kernels/$f.hip -o $T/$f.o 2>/dev/null & done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -fno-gpu-sanitize -o $T/libcrt_asan.so $T/*.o -lpthread
 cd $R
@@ -20,7 +20,7 @@ echo "ASan / UBSan reports: $(grep -c 'runtime error\|ERROR: AddressSanitizer' $
 T2=${TMPDIR:-/tmp}/crt_tsan; mkdir -p $T2; cd $R/crust-render_amd/csrc
 F2="--offload-arch=gfx950 -g -fPIC -std=c++17 -ffp-contract=off -fno-fast-math -I../../include -fsanitize=thread -fno-gpu-sanitize -fno-omit-frame-pointer"
 for f in bvh_build scene capi; do /opt/rocm/bin/hipcc $F2 -O1 -x hip -c $f.cpp -o $T2/$f.o 2>/dev/null & done
-for f in traverse pathtrace; do /opt/rocm/bin/hipcc $F2 -O2 -fno-slp-vectorize -c kernels/$f.hip -o $T2/$f.o 2>/dev/null & done
+for f in traverse pathtrace shade_seam gather; do /opt/rocm/bin/hipcc $F2 -O2 -fno-slp-vectorize -c kernels/$f.hip -o $T2/$f.o 2>/dev/null & done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=thread -fno-gpu-sanitize -o $T2/libcrt_tsan.so $T2/*.o -lpthread
 cd $R
