@@ -98,9 +98,12 @@ def sim_A(all_steps, refill=32):
     return instr, useful
 
 
-def sim_affine(all_tr, rows=2, rare_min=16, overhead=20, fetch_min=32, chain_min=0):
+def sim_affine(all_tr, rows=2, rare_min=16, overhead=20, fetch_min=32, chain_min=0, retire=False, emit_min=None):
     """State in LDS but slot r is only ever processed by lane r % 64 (conflict-free LDS, no gather list): a lane
-    runs the chosen phase for at most one of its `rows` slots per step."""
+    runs the chosen phase for at most one of its `rows` slots per step. retire=True: ONE phase emits a finished ray's hit
+    and, in the same step, fetches and sets up the next ray into the slot (while input remains) — the slot does not wait
+    for a second scheduling round, at the price of a step that runs both pieces of code. emit_min: lanes that must be
+    waiting to emit before the emit / retire phase is chosen over node / packet work (the shipped kernel: 40)."""
     instr = useful = 0
     n = len(all_tr); nxt = 0
     slots = [[None] * rows for _ in range(64)]
@@ -108,7 +111,7 @@ def sim_affine(all_tr, rows=2, rare_min=16, overhead=20, fetch_min=32, chain_min
         free = [(l, k) for l in range(64) for k in range(rows) if slots[l][k] is None]
         live = [slots[l][k] for l in range(64) for k in range(rows) if slots[l][k] is not None]
         lanes_free = len({l for l, _ in free})
-        if nxt < n and (lanes_free >= fetch_min or not live):
+        if nxt < n and ((lanes_free >= fetch_min and not (retire and live)) or not live):
             got = 0
             seen = set()
             for l, k in free:
@@ -127,7 +130,7 @@ def sim_affine(all_tr, rows=2, rare_min=16, overhead=20, fetch_min=32, chain_min
             for p in phs:
                 cnt[p] = cnt.get(p, 0) + 1
         common = {p: v for p, v in cnt.items() if p in "NP"}
-        rare = {p: v for p, v in cnt.items() if p not in "NP" and v >= rare_min}
+        rare = {p: v for p, v in cnt.items() if p not in "NP" and v >= (emit_min if (emit_min and p == "E") else rare_min)}
         cand = rare or common or cnt
         ph = max(cand.items(), key=lambda kv: kv[1])[0]
         k_run = 0
@@ -138,11 +141,15 @@ def sim_affine(all_tr, rows=2, rare_min=16, overhead=20, fetch_min=32, chain_min
                 if r is not None and ph_of(r) == ph:
                     if ph == "E":
                         slots[l][k] = None
+                        if retire and nxt < n:
+                            slots[l][k] = [all_tr[nxt], 0]; nxt += 1
                     else:
                         r[1] += 1
                         ran.append(r)
                     k_run += 1
                     break
+        if ph == "E" and retire:
+            instr += COST["F"]; useful += COST["F"] * k_run
         instr += COST[ph] + overhead; useful += COST[ph] * k_run
         # chaining: while enough of the rays that just ran agree on their next common phase, run it at once
         # (state stays in registers: no scheduling round, no LDS round trip)
@@ -266,6 +273,12 @@ def main():
             ("D 2 rows, ovh 90, chain>=32", sim_affine(tr, rows=2, overhead=90, chain_min=32)),
             ("D 2 rows, ovh 90, chain>=16", sim_affine(tr, rows=2, overhead=90, chain_min=16)),
             ("D 2 rows, ovh 90, chain>=40", sim_affine(tr, rows=2, overhead=90, chain_min=40)),
+            # round 4, for the next round: emit and fetch as ONE phase (a finished ray's slot is refilled in the step that
+            # reports its hit), against the shipped form with the same emit threshold
+            ("D shipped form, emit>=40", sim_affine(tr, rows=2, overhead=90, chain_min=24, fetch_min=40, emit_min=40)),
+            ("D retire (emit+fetch), >=40", sim_affine(tr, rows=2, overhead=90, chain_min=24, fetch_min=40, emit_min=40, retire=True)),
+            ("D retire (emit+fetch), >=24", sim_affine(tr, rows=2, overhead=90, chain_min=24, fetch_min=40, emit_min=24, retire=True)),
+            ("D retire (emit+fetch), >=16", sim_affine(tr, rows=2, overhead=90, chain_min=24, fetch_min=40, emit_min=16, retire=True)),
         ):
             print(f"   {name:28s} wave-instr/ray {ins / len(tr):7.2f}   lane utilisation {use / (64.0 * ins):5.3f}")
 
