@@ -77,7 +77,19 @@ def build_host(out_dir):
     return exe
 
 
-def run_host(exe, blob, tmp_dir, env=None):
+def build_rccl_host(out_dir):
+    """hipcc (the host calls HIP and RCCL itself) -> path of examples/host_rccl's executable."""
+    exe = os.path.join(str(out_dir), "crt_rccl_host")
+    lib_dir = os.path.join(ROOT, "crust-render_amd")
+    cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "host_rccl", "crt_rccl_host.cpp"), "-L", lib_dir, "-lcrt_amd", "-L/opt/rocm/lib",
+           "-lrccl", "-Wl,-rpath," + lib_dir, "-o", exe]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    return exe
+
+
+def run_host(exe, blob, tmp_dir, env=None, timeout=300):
     """-> (CompletedProcess, film path)."""
     scene, film = os.path.join(str(tmp_dir), "scene.bin"), os.path.join(str(tmp_dir), "film.bin")
     with open(scene, "wb") as f:
@@ -86,4 +98,4 @@ def run_host(exe, blob, tmp_dir, env=None):
         os.remove(film)
     e = dict(os.environ)
     e.update(env or {})
-    return subprocess.run([exe, scene, film], capture_output=True, text=True, timeout=600, env=e), film
+    return subprocess.run([exe, scene, film], capture_output=True, text=True, timeout=timeout, env=e), film

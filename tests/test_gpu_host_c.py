@@ -55,3 +55,35 @@ def test_the_c_host_renders_what_the_python_host_and_the_oracle_render(crt, exe,
         assert int(st[k]) == getattr(pst, f) == getattr(ost, f), (name, f, int(st[k]), getattr(pst, f), getattr(ost, f))
     assert np.array_equal(img.view(np.uint32), pimg.view(np.uint32)), name
     assert np.array_equal(img.view(np.uint32), oimg.view(np.uint32)), name
+
+
+@pytest.mark.parametrize("name,w,h,depth,spp,batch", [("veach_mis", 100, 54, 8, 6, 4), ("instancing", 96, 54, 8, 4, 4)])
+def test_the_rccl_host_runs_its_collectives_and_assembles_the_same_frame(crt, tmp_path, name, w, h, depth, spp, batch):
+    """examples/host_rccl/crt_rccl_host.cpp at WORLD_SIZE = 1 (all a one-GPU box can run): ncclCommInitRank, the padded
+    shard through ncclAllGather, crt_gather_plan_assemble, the counters through ncclAllReduce — RCCL executing on the
+    device, driven by a native host through the C ABI; frame and counters equal the Python host's. (The multi-rank
+    index plan itself is covered by test_gather_plan_on_device at world 2 / 3 / 8.)"""
+    import torch
+    exe_rccl = hc.build_rccl_host(tmp_path)
+    desc = crt.usda.load(os.path.join(ROOT, "scenes", name + ".usda"), w, h)
+    desc.settings["max_depth"] = depth
+    scene, mats, _protos = crt.usda.build_world(desc, crt, crt.default_material)
+    res, film = hc.run_host(exe_rccl, hc.scene_blob(crt, desc, mats, spp, batch), tmp_path,
+                            {"RANK": "0", "WORLD_SIZE": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "NCCL_SOCKET_IFNAME": "lo"},
+                            timeout=150)
+    assert res.returncode == 0, (res.returncode, res.stdout[-500:], res.stderr[-2000:])
+    assert "world 1, RCCL" in res.stdout, res.stdout
+    raw = np.fromfile(film, dtype=np.uint8)
+    img = raw[:w * h * 12].view(np.float32).reshape(h, w, 3)
+    st = raw[w * h * 12:].view(np.uint64)
+    s = desc.settings
+    settings = crt.RenderSettings(s["width"], s["height"], s["max_depth"], s["frame"], s["strategy"], s["filter"],
+                                  s["filter_radius"], 0.0)
+    r = crt.Renderer(scene, mats, desc.lights, crt.make_camera(**desc.camera), settings)
+    for b in range(0, spp, batch):
+        r.render_samples(b, min(batch, spp - b))
+    torch.cuda.synchronize()
+    pimg, pst = r.image(), r.stats()
+    for k, (f, _t) in enumerate(ora.RayStats._fields_):
+        assert int(st[k]) == getattr(pst, f), (name, f)
+    assert np.array_equal(img.view(np.uint32), pimg.view(np.uint32)), name

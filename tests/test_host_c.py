@@ -39,3 +39,17 @@ def test_the_c_host_rejects_a_truncated_scene_file(exe, tmp_path):
     for cut in (3, 40, len(blob) // 2, len(blob) - 4):
         res, film = hc.run_host(exe, blob[:cut], tmp_path)
         assert res.returncode == 2 and not os.path.exists(film), (cut, res.returncode, res.stderr)
+
+
+def test_the_rccl_host_builds_and_needs_a_device(tmp_path):
+    """examples/host_rccl/crt_rccl_host.cpp (one process per GPU, ncclAllGather + crt_gather_plan_assemble driven by the
+    host) compiles against include/crt.h + <rccl/rccl.h>; without a device it stops before any collective."""
+    import torch
+    exe_rccl = hc.build_rccl_host(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("a device is present: tests/test_gpu_host_c.py runs it")
+    crt = importlib.import_module("crust-render_amd")
+    res, film = hc.run_host(exe_rccl, _blob(crt, "cornellbox", 16, 16, 4, 1, 1), tmp_path)
+    assert res.returncode == 3 and "no HIP device" in res.stderr and not os.path.exists(film), (res.returncode, res.stderr)
+    res, _ = hc.run_host(exe_rccl, _blob(crt, "cornellbox", 16, 16, 4, 1, 1), tmp_path, {"RANK": "2", "WORLD_SIZE": "2"})
+    assert res.returncode == 2 and "bad RANK" in res.stderr
