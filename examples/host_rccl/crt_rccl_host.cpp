@@ -12,7 +12,10 @@
 //   the job's RayStats: one ncclAllReduce of the eight 64-bit counters
 // Rank 0 writes the frame and the counters (the format of ../host_c/crt_host.c). The ncclUniqueId travels through a file
 // (rank 0 writes it, the others wait for it): no MPI, no Python. With WORLD_SIZE=1 the same calls run on one GPU — that
-// is the case tests/test_gpu_host_rccl.py can run on a one-GPU box; the frame must equal the single-process hosts'.
+// is the case tests/test_gpu_host_c.py can run on a one-GPU box; the frame must equal the single-process hosts'.
+// CRT_RCCL_LOOPBACK=1 (tests): ONE process plays every rank in turn — each rank's renderer, its shard resolved to where
+// the all-gather would have put it (recv + rank x padded x 3), counters summed on the host — and no communicator is
+// made: the multi-rank data layout of this file, checked on a box where RCCL cannot take two ranks.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -28,6 +31,7 @@
 #define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "crt_rccl_host: %s: %s\n", #x, hipGetErrorString(e_)); return 3; } } while (0)
 #define NCCL_OK(x) do { ncclResult_t e_ = (x); if (e_ != ncclSuccess) { fprintf(stderr, "crt_rccl_host: %s: %s\n", #x, ncclGetErrorString(e_)); return 3; } } while (0)
 
+static_assert(sizeof(CrtRayStats) == 64, "eight 64-bit counters");
 static int env_int(const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; }
 
 // rank 0 creates the id and publishes it (write to a temporary name, then rename: readers never see half a file)
@@ -70,16 +74,24 @@ int main(int argc, char **argv) {
   hipStream_t stream;
   HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
 
+  const bool loopback = env_int("CRT_RCCL_LOOPBACK", 0) != 0;
   ncclUniqueId id;
-  if (const int e = exchange_id(&id, rank, world)) return e;
-  ncclComm_t comm;
-  NCCL_OK(ncclCommInitRank(&comm, world, id, rank));
+  ncclComm_t comm = nullptr;
+  if (!loopback) {
+    if (const int e = exchange_id(&id, rank, world)) return e;
+    NCCL_OK(ncclCommInitRank(&comm, world, id, rank));
+  }
 
   const CrtRenderSettings settings = w.settings;
-  CrtRenderer *r = crt_renderer_new(w.scene, w.materials, w.n_geoms, w.lights, w.n_lights, &w.camera, &settings, (uint32_t)rank, (uint32_t)world);
-  if (!r) return fail_lib("crt_renderer_new");
-  for (uint32_t s = 0; s < w.spp; s += w.batch)
-    if (crt_render_samples(r, s, w.spp - s < w.batch ? w.spp - s : w.batch, stream) != CRT_OK) return fail_lib("crt_render_samples");
+  auto render_rank = [&](int rk) -> CrtRenderer * {
+    CrtRenderer *rr = crt_renderer_new(w.scene, w.materials, w.n_geoms, w.lights, w.n_lights, &w.camera, &settings, (uint32_t)rk, (uint32_t)world);
+    if (!rr) { fail_lib("crt_renderer_new"); return nullptr; }
+    for (uint32_t s = 0; s < w.spp; s += w.batch)
+      if (crt_render_samples(rr, s, w.spp - s < w.batch ? w.spp - s : w.batch, stream) != CRT_OK) { fail_lib("crt_render_samples"); crt_renderer_free(rr); return nullptr; }
+    return rr;
+  };
+  CrtRenderer *r = render_rank(loopback ? 0 : rank);
+  if (!r) return 3;
 
   // the shard, zero-padded to the common length; one all-gather; one scatter into the frame
   const size_t own = crt_renderer_pixel_count(r), padded = crt_shard_padded_count(settings.width, settings.height, (uint32_t)world);
@@ -95,14 +107,31 @@ int main(int argc, char **argv) {
   HIP_OK(hipMalloc(&d_stats, 64));
   HIP_OK(hipMemsetAsync(d_send, 0, padded * 12, stream));
   HIP_OK(hipMemsetAsync(d_frame, 0, n_pix * 12, stream));
-  if (crt_film_resolve(r, d_send, stream) != CRT_OK) return fail_lib("crt_film_resolve");
-  NCCL_OK(ncclAllGather(d_send, d_recv, padded * 3, ncclFloat, comm, stream));
-  if (crt_gather_plan_assemble(plan, d_recv, d_frame, stream) != CRT_OK) return fail_lib("crt_gather_plan_assemble");
-
   CrtRayStats mine;
-  if (crt_render_stats(r, &mine) != CRT_OK) return fail_lib("crt_render_stats");  // drains the batches' stream
-  HIP_OK(hipMemcpyAsync(d_stats, &mine, 64, hipMemcpyHostToDevice, stream));
-  NCCL_OK(ncclAllReduce(d_stats, d_stats, 8, ncclUint64, ncclSum, comm, stream));
+  if (!loopback) {
+    if (crt_film_resolve(r, d_send, stream) != CRT_OK) return fail_lib("crt_film_resolve");
+    NCCL_OK(ncclAllGather(d_send, d_recv, padded * 3, ncclFloat, comm, stream));
+    if (crt_render_stats(r, &mine) != CRT_OK) return fail_lib("crt_render_stats");  // drains the batches' stream
+    HIP_OK(hipMemcpyAsync(d_stats, &mine, 64, hipMemcpyHostToDevice, stream));
+    NCCL_OK(ncclAllReduce(d_stats, d_stats, 8, ncclUint64, ncclSum, comm, stream));
+  } else {  // every rank's shard where the all-gather would have put it; the counters' sum on the host
+    HIP_OK(hipMemsetAsync(d_recv, 0, (size_t)world * padded * 12, stream));
+    unsigned long long sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int rk = 0; rk < world; rk++) {
+      CrtRenderer *rr = rk == 0 ? r : render_rank(rk);
+      if (!rr) return 3;
+      if (crt_renderer_pixel_count(rr) > padded) return 3;
+      if (crt_film_resolve(rr, d_recv + (size_t)rk * padded * 3, stream) != CRT_OK) return fail_lib("crt_film_resolve");
+      if (crt_render_stats(rr, &mine) != CRT_OK) return fail_lib("crt_render_stats");
+      const unsigned long long *m = reinterpret_cast<const unsigned long long *>(&mine);
+      for (int k = 0; k < 8; k++) sum[k] += m[k];
+      HIP_OK(hipStreamSynchronize(stream));
+      if (rk != 0) crt_renderer_free(rr);
+    }
+    HIP_OK(hipMemcpyAsync(d_stats, sum, 64, hipMemcpyHostToDevice, stream));
+    HIP_OK(hipStreamSynchronize(stream));  // `sum` leaves scope
+  }
+  if (crt_gather_plan_assemble(plan, d_recv, d_frame, stream) != CRT_OK) return fail_lib("crt_gather_plan_assemble");
 
   std::vector<float> frame(n_pix * 3);
   CrtRayStats total;
@@ -115,11 +144,12 @@ int main(int argc, char **argv) {
     fclose(o);
     int ver = 0;
     ncclGetVersion(&ver);
-    printf("crt_rccl_host: world %d, RCCL %d: %ux%u, %u spp; all-gather of %zu x 3 floats per rank; %llu closest-hit + %llu shadow rays in all\n",
-           world, ver, settings.width, settings.height, w.spp, padded, (unsigned long long)total.closest_hit,
+    printf("crt_rccl_host: world %d%s, RCCL %d: %ux%u, %u spp; all-gather of %zu x 3 floats per rank; %llu closest-hit + %llu shadow rays in all\n",
+           world, loopback ? " (loopback: one process plays every rank, no communicator)" : "", ver, settings.width, settings.height, w.spp,
+           padded, (unsigned long long)total.closest_hit,
            (unsigned long long)total.shadow_rays);
   }
-  ncclCommDestroy(comm);
+  if (comm) ncclCommDestroy(comm);
   crt_gather_plan_free(plan);
   crt_renderer_free(r);
   (void)hipFree(d_send); (void)hipFree(d_recv); (void)hipFree(d_frame); (void)hipFree(d_stats);

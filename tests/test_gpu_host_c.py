@@ -87,3 +87,23 @@ def test_the_rccl_host_runs_its_collectives_and_assembles_the_same_frame(crt, tm
     for k, (f, _t) in enumerate(ora.RayStats._fields_):
         assert int(st[k]) == getattr(pst, f), (name, f)
     assert np.array_equal(img.view(np.uint32), pimg.view(np.uint32)), name
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_the_rccl_hosts_multi_rank_layout_in_loopback(crt, exe, tmp_path, world):
+    """RCCL does not take two ranks on one GPU (profiles/r04_rccl_two_ranks.txt), so the native host's multi-rank data
+    layout — every rank's renderer, its shard at recv + rank x padded x 3, crt_gather_plan_assemble, the counters' sum —
+    runs with ONE process playing every rank (CRT_RCCL_LOOPBACK=1: no communicator): frame and counters must equal the
+    single-process C host's on an odd frame size."""
+    exe_rccl = hc.build_rccl_host(tmp_path)
+    desc = crt.usda.load(os.path.join(ROOT, "scenes", "veach_mis.usda"), 117, 61)
+    desc.settings["max_depth"] = 8
+    _scene, mats, _protos = crt.usda.build_world(desc, crt, crt.default_material)
+    blob = hc.scene_blob(crt, desc, mats, 6, 3)
+    one_dir, many_dir = tmp_path / "one", tmp_path / "many"
+    one_dir.mkdir(); many_dir.mkdir()
+    res1, film1 = hc.run_host(exe, blob, one_dir)
+    resn, filmn = hc.run_host(exe_rccl, blob, many_dir, {"RANK": "0", "WORLD_SIZE": str(world), "CRT_RCCL_LOOPBACK": "1"}, timeout=150)
+    assert res1.returncode == 0 and resn.returncode == 0, (res1.stderr[-500:], resn.stderr[-1500:])
+    assert "loopback" in resn.stdout
+    assert np.array_equal(np.fromfile(film1, dtype=np.uint8), np.fromfile(filmn, dtype=np.uint8)), world
