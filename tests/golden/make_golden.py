@@ -6,6 +6,8 @@ and tests/scenes.py; the files hold the expected OUTPUTS.
   traverse_<scene>.npz  256 rays of the scene's standard batch -> t,u,v,normal (float bits), geom/prim ids, front,
                         occluded flags, for [0.001, inf)
   render_<scene>.npz    small forward-mode render -> image float bits + the eight RayStats counters
+  seam_calls.npz        192 Material calls per lobe class (scatter_importance, eval, emitted_directional) and 768 Light calls
+                        (sample_li, pdf_at_point, escaped) -> the result records' bits (include/crt.h layouts)
 
 The oracle is pinned by the reference's known-answer tests (tests/test_oracle_rt.py, tests/test_oracle_shade.py);
 these files freeze its outputs so that a later change to either side shows up as a diff against fixed data."""
@@ -42,6 +44,19 @@ def main():
         img, st = o.render(spp, forward=1)
         counters = np.array([getattr(st, f) for f, _ in ora.RayStats._fields_], dtype=np.uint64)
         np.savez_compressed(os.path.join(HERE, f"render_{name}.npz"), image_bits=img.view(np.uint32), counters=counters)
+    import seam_cases as sc
+    drv = sc.oracle_drivers()
+    out = {}
+    for cls in sc.CLASSES:
+        mats, q = gi.seam_material_case(cls)
+        out[cls + "_scatter"] = drv.scatter(mats, q).view(np.uint32)
+        out[cls + "_eval"] = drv.eval(mats, q).view(np.uint32)
+        out[cls + "_emitted"] = drv.emitted(mats, q).view(np.uint32)
+    table, q = gi.seam_light_case()
+    out["light_sample"] = drv.light_sample(table, q).view(np.uint32)
+    out["light_pdf"] = drv.light_pdf(table, q).view(np.uint32)
+    out["light_escaped"] = drv.light_escaped(table, q).view(np.uint32)
+    np.savez_compressed(os.path.join(HERE, "seam_calls.npz"), **out)
     print("golden vectors written to", HERE)
 
 

@@ -74,3 +74,46 @@ def test_gpu_render_matches_golden(crt, name, w, h, spp, depth):
     assert np.array_equal(r.image().view(np.uint32), g["image_bits"])
     st = r.stats()
     assert [getattr(st, f) for f, _ in ora.RayStats._fields_] == g["counters"].tolist()
+
+
+# ---- the shading seam's functions: result records of seeded calls, frozen ----
+def _seam_sides(drivers):
+    import seam_cases as sc
+    g = _g("seam_calls")
+    for cls in sc.CLASSES:
+        mats, q = gi.seam_material_case(cls)
+        for name in ("scatter", "eval", "emitted"):
+            got = np.ascontiguousarray(getattr(drivers, name)(mats, q)).view(np.uint32).reshape(len(q), -1)
+            assert len(sc.mismatches(got, g[cls + "_" + name].reshape(len(q), -1))) == 0, (cls, name)  # NaN == NaN, else bits
+    table, q = gi.seam_light_case()
+    for name in ("light_sample", "light_pdf", "light_escaped"):
+        got = np.ascontiguousarray(getattr(drivers, name)(table, q)).view(np.uint32).reshape(len(q), -1)
+        assert len(sc.mismatches(got, g[name].reshape(len(q), -1))) == 0, name
+
+
+def test_oracle_seam_functions_match_golden():
+    import seam_cases as sc
+    _seam_sides(sc.oracle_drivers())
+
+
+@pytest.mark.gpu
+def test_gpu_seam_functions_match_golden(crt):
+    import seam_cases as sc
+
+    class Device:  # crt_material_*_n / crt_light_*_n on numpy records
+        @staticmethod
+        def _mats(mats):
+            return crt.shading.DeviceMaterials([crt.CrtMaterial.from_buffer_copy(m.tobytes()) for m in mats])
+
+        @staticmethod
+        def _lights(table):
+            return crt.shading.DeviceLights((crt.CrtLight * len(table)).from_buffer_copy(table.tobytes()))
+
+        def scatter(self, mats, q): return self._mats(mats).scatter_importance(crt.shading.to_device(q)).cpu().numpy()
+        def eval(self, mats, q): return self._mats(mats).eval(crt.shading.to_device(q)).cpu().numpy()
+        def emitted(self, mats, q): return self._mats(mats).emitted_directional(crt.shading.to_device(q)).cpu().numpy()
+        def light_sample(self, t, q): return self._lights(t).sample_li(crt.shading.to_device(q)).cpu().numpy()
+        def light_pdf(self, t, q): return self._lights(t).pdf_at_point(crt.shading.to_device(q)).cpu().numpy()
+        def light_escaped(self, t, q): return self._lights(t).escaped(crt.shading.to_device(q)).cpu().numpy()
+
+    _seam_sides(Device())
