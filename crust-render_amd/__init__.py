@@ -29,7 +29,7 @@ INF = float("inf")
 
 CRT_OK = 0
 _ERRORS = {-1: "CRT_ERR_BAD_ARG", -2: "CRT_ERR_BAD_ID", -3: "CRT_ERR_NO_DEVICE", -4: "CRT_ERR_STACK",
-           -5: "CRT_ERR_UNSUPPORTED"}
+           -5: "CRT_ERR_UNSUPPORTED", -6: "CRT_ERR_NO_MEMORY"}
 
 
 class CrtError(RuntimeError):

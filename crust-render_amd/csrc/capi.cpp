@@ -6,6 +6,7 @@
 #include <cstring>
 #include <exception>
 #include <new>
+#include <stdexcept>
 #include <unordered_set>
 
 #include "crt_internal.h"
@@ -70,39 +71,48 @@ CrtBuilder *crt_builder_new(void) { return new (std::nothrow) CrtBuilder(); }
 void crt_builder_free(CrtBuilder *b) { delete b; }
 int crt_reserve(CrtBuilder *b, size_t additional) {
   if (!b) return CRT_ERR_BAD_ARG;
-  b->b.geoms.reserve(b->b.geoms.size() + additional);
-  return CRT_OK;
+  return abi_guard("crt_reserve", [&] {
+    if (additional > b->b.geoms.max_size() - b->b.geoms.size()) throw std::length_error("capacity overflow");  // Vec::reserve panics on it
+    b->b.geoms.reserve(b->b.geoms.size() + additional);
+    return (int)CRT_OK;
+  });
 }
 size_t crt_count(const CrtBuilder *b) { return b ? b->b.geoms.size() : 0; }
 
 int crt_attach_triangles(CrtBuilder *b, const float *verts, size_t n_verts, const uint32_t *indices, size_t n_tris,
                          const float *normals, size_t n_normals, uint32_t mask, uint32_t *geom_id_out) {
   if (!b || (n_verts && !verts) || (n_tris && !indices)) return CRT_ERR_BAD_ARG;
-  Geom g;
-  g.mask = mask;
-  fill_mesh(g, verts, n_verts, indices, n_tris, normals, n_normals);
-  b->b.geoms.push_back(std::move(g));
-  if (geom_id_out) *geom_id_out = uint32_t(b->b.geoms.size() - 1);
-  return CRT_OK;
+  return abi_guard("crt_attach_triangles", [&] {
+    Geom g;
+    g.mask = mask;
+    fill_mesh(g, verts, n_verts, indices, n_tris, normals, n_normals);
+    b->b.geoms.push_back(std::move(g));
+    if (geom_id_out) *geom_id_out = uint32_t(b->b.geoms.size() - 1);
+    return (int)CRT_OK;
+  });
 }
 int crt_attach_sphere(CrtBuilder *b, const float center[3], float radius, uint32_t mask, uint32_t *geom_id_out) {
   if (!b || !center) return CRT_ERR_BAD_ARG;
-  Geom g;
-  g.mask = mask;
-  fill_sphere(g, center, radius);
-  b->b.geoms.push_back(std::move(g));
-  if (geom_id_out) *geom_id_out = uint32_t(b->b.geoms.size() - 1);
-  return CRT_OK;
+  return abi_guard("crt_attach_sphere", [&] {
+    Geom g;
+    g.mask = mask;
+    fill_sphere(g, center, radius);
+    b->b.geoms.push_back(std::move(g));
+    if (geom_id_out) *geom_id_out = uint32_t(b->b.geoms.size() - 1);
+    return (int)CRT_OK;
+  });
 }
 int crt_attach_instance(CrtBuilder *b, CrtScene *scene, const float l2w[12], const float *l2w_end, uint32_t mask,
                         uint32_t *geom_id_out) {
   if (!b || !scene || !l2w) return CRT_ERR_BAD_ARG;
-  Geom g;
-  g.mask = mask;
-  fill_instance(g, scene, l2w, l2w_end);
-  b->b.geoms.push_back(std::move(g));
-  if (geom_id_out) *geom_id_out = uint32_t(b->b.geoms.size() - 1);
-  return CRT_OK;
+  return abi_guard("crt_attach_instance", [&] {
+    Geom g;
+    g.mask = mask;
+    fill_instance(g, scene, l2w, l2w_end);
+    b->b.geoms.push_back(std::move(g));
+    if (geom_id_out) *geom_id_out = uint32_t(b->b.geoms.size() - 1);
+    return (int)CRT_OK;
+  });
 }
 int crt_attach_empty(CrtBuilder *b, uint32_t mask, uint32_t *geom_id_out) {
   return crt_attach_triangles(b, nullptr, 0, nullptr, 0, nullptr, 0, mask, geom_id_out);
@@ -111,8 +121,13 @@ int crt_set_triangles(CrtBuilder *b, uint32_t id, const float *verts, size_t n_v
                       size_t n_tris, const float *normals, size_t n_normals) {
   if (!b || (n_verts && !verts) || (n_tris && !indices)) return CRT_ERR_BAD_ARG;
   if (id >= b->b.geoms.size()) return CRT_ERR_BAD_ID;
-  fill_mesh(b->b.geoms[id], verts, n_verts, indices, n_tris, normals, n_normals);
-  return CRT_OK;
+  return abi_guard("crt_set_triangles", [&] {
+    Geom g;  // built aside: the slot keeps its old geometry if an allocation fails
+    g.mask = b->b.geoms[id].mask;
+    fill_mesh(g, verts, n_verts, indices, n_tris, normals, n_normals);
+    b->b.geoms[id] = std::move(g);
+    return (int)CRT_OK;
+  });
 }
 int crt_set_sphere(CrtBuilder *b, uint32_t id, const float center[3], float radius) {
   if (!b || !center) return CRT_ERR_BAD_ARG;

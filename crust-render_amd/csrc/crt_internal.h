@@ -241,7 +241,7 @@ inline bool wide_split(const DevScene &s, bool renderer = false) {
 // launch goes through the EngineSelect it returns — an engine instance never meets an image form it was not built for
 // (rounds 2 and 3 each lost a GPU box to exactly that: profiles/README.md, "The r02f abort", "The r03w fault").
 struct EngineSelect {
-  bool wide = false;       // the four-workgroups-per-CU kernels (WIDE): no direct form, three LDS stack entries
+  bool wide = false;       // the four-workgroups-per-CU kernels (WIDE): the flat engine copy, 3-5 LDS stack entries (lds_stack)
   bool wide_direct = false;  // ... their instances that hold the DIRECT engine copy only (WIDE = 2): direct-leaf images
   bool direct = false;     // the DIRECT engine copy of the three-wave kernels: reads direct child words, root test at entry
   uint32_t lds_stack = CRT_POOL_STACK;  // stack entries per ray in LDS
@@ -371,6 +371,16 @@ int launch_occluded_n(const DevScene &s, const CrtRay *d_rays, size_t n, float t
 int device_ok();
 // printf-style text for crt_last_error() on this thread (failures that are not HIP calls).
 void set_error_text(const char *fmt, ...);
+// Nothing may unwind through the C ABI — a host in C or Rust cannot catch it, and unwinding into its frames is undefined:
+// an entry point whose body allocates host memory (std containers) runs it through abi_guard; a failed allocation (or a
+// length_error: crt_reserve(b, SIZE_MAX)) becomes CRT_ERR_NO_MEMORY with the reason in crt_last_error.
+template <class F>
+inline int abi_guard(const char *what, F &&body) noexcept {
+  try { return body(); }
+  catch (const std::exception &e) { set_error_text("%s: %s", what, e.what()); }
+  catch (...) { set_error_text("%s: unknown failure", what); }
+  return CRT_ERR_NO_MEMORY;
+}
 
 // Records the failing HIP call for crt_last_error() and returns false.
 bool hip_failed(int /*hipError_t*/ err, const char *what, const char *file, int line);

@@ -49,10 +49,15 @@ CrtGatherPlan *crt_gather_plan_new(uint32_t width, uint32_t height, uint32_t wor
   if (!p) return nullptr;
   p->width = width; p->height = height; p->world = world;
   p->padded = crt_shard_padded_count(width, height, world);
-  std::vector<uint32_t> idx((size_t)world * p->padded, CRT_INVALID_ID);
-  for (uint32_t r = 0; r < world; r++) crt_shard_pixels(width, height, r, world, idx.data() + (size_t)r * p->padded);
-  if (!CRT_HIP_OK(hipMalloc(&p->d_index, idx.size() * 4)) ||
-      !CRT_HIP_OK(hipMemcpy(p->d_index, idx.data(), idx.size() * 4, hipMemcpyHostToDevice))) {
+  const int rc = abi_guard("crt_gather_plan_new", [&] {  // the host copy of the index plan is a std::vector
+    std::vector<uint32_t> idx((size_t)world * p->padded, CRT_INVALID_ID);
+    for (uint32_t r = 0; r < world; r++) crt_shard_pixels(width, height, r, world, idx.data() + (size_t)r * p->padded);
+    return CRT_HIP_OK(hipMalloc(&p->d_index, idx.size() * 4)) &&
+                   CRT_HIP_OK(hipMemcpy(p->d_index, idx.data(), idx.size() * 4, hipMemcpyHostToDevice))
+               ? (int)CRT_OK
+               : (int)CRT_ERR_NO_DEVICE;
+  });
+  if (rc != CRT_OK) {
     if (p->d_index) (void)hipFree(p->d_index);
     delete p;
     return nullptr;

@@ -1168,10 +1168,11 @@ struct Renderer {
   // `stage_min_paths` paths up. CRT_FUSED / CRT_WIDE / CRT_STAGE_MIN_PATHS override (A/B, per-stage timing, tests).
   EngineSelect engine;     // which traversal-engine instance runs this scene's image (crt_internal.h, select_engine)
   bool wide = false;       // = engine.wide: per-stage launches run the four-wave traversal kernels
-  // The scene prefers one launch per stage for large batches: small flat triangle scenes (the four-wave kernels), and —
-  // round 4 — instance-heavy scenes and large trees on the three-wave kernels: their lanes then overlap launches of
-  // different stages and bounces, which one fused launch per lane cannot (1080p / 4K, Mray/s fused -> per-stage: stress
-  // 2460 -> 2559, PointInstancedMedCity 2191 -> 2224, the 7 M-triangle synthetic scene 3307 -> 3400; profiles/README.md).
+  // The scene prefers one launch per stage for large batches — since round 4 every scene does: the lanes then overlap
+  // launches of different stages and bounces, which one fused launch per lane cannot (measured first on the three-wave
+  // kernels, 1080p / 4K, Mray/s fused -> per-stage: stress 2460 -> 2559, PointInstancedMedCity 2191 -> 2224, the
+  // 7 M-triangle synthetic scene 3307 -> 3400; the per-stage traversal kernels are the four-wave instances select_engine
+  // names — flat engine copy or, for direct-leaf images, the direct one; profiles/README.md).
   bool prefer_stage = false;
   bool cam_compact_ok = true;  // CRT_CAM_COMPACT
   int shade_wide = -1;            // CRT_SHADE_WIDE: 0 = the three-wave shade kernels even beside four-wave traversal kernels (A/B)
@@ -1560,9 +1561,11 @@ void crt_camera_new(CrtCamera *c, const float lookfrom[3], const float lookat[3]
   c->lens_radius = aperture / 2.0f;
 }
 
-CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, size_t n_materials, const CrtLight *lights,
-                              size_t n_lights, const CrtCamera *camera, const CrtRenderSettings *settings,
-                              uint32_t tile_rank, uint32_t tile_world) {
+// The body of crt_renderer_new; it may throw (std containers of the pixel list, the material table's deduplication): the
+// entry point below catches, `hold` frees what was built.
+static CrtRenderer *renderer_new(CrtScene *scene, const CrtMaterial *materials, size_t n_materials, const CrtLight *lights,
+                                 size_t n_lights, const CrtCamera *camera, const CrtRenderSettings *settings,
+                                 uint32_t tile_rank, uint32_t tile_world) {
   if (!scene || !camera || !settings || (n_materials && !materials) || (n_lights && !lights)) return nullptr;
   if (tile_world == 0 || tile_rank >= tile_world) return nullptr;
   if (!(settings->variance_threshold >= 0.0f)) return nullptr;
@@ -1571,6 +1574,7 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
   if (scene->p->ensure_device() != CRT_OK) return nullptr;
   CrtRenderer *R = new (std::nothrow) CrtRenderer();
   if (!R) return nullptr;
+  struct Hold { CrtRenderer *p; ~Hold() { delete p; } } hold{R};  // every way out but the last frees the renderer
   const Knobs knobs = read_knobs();
   Renderer &r = R->r;
   r.scene = scene->p;
@@ -1670,7 +1674,7 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
     }
     if (d_count) (void)hipFree(d_count);
   }
-  if (!ok) { delete R; return nullptr; }
+  if (!ok) return nullptr;
   {
     bool simple = true;
     for (size_t k = 0; k < n_materials; k++) simple = simple && material_class(materials[k]) <= 1;
@@ -1691,7 +1695,6 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
   // honours only where the image can be decoded by what was asked for (never the four-wave kernels on direct words)
   if (select_engine_env(P.scene, r.engine, true) != CRT_OK) {
     set_error_text("crt_renderer_new: no traversal-engine instance of this build can decode the scene image");
-    delete R;
     return nullptr;
   }
   r.wide = r.engine.wide;
@@ -1714,6 +1717,17 @@ CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, siz
   if (knobs.grid_mult > 0) { r.fused_mult = r.stage_mult = knobs.grid_mult; r.mult_forced = 1; }  // CRT_GRID_MULT: tuning knob
   r.fused = r.force_fused >= 0 ? r.force_fused != 0 : !r.prefer_stage;  // until the first batch: the scene's preference
   r.grid = r.batch_grid(0, r.fused);
+  hold.p = nullptr;
+  return R;
+}
+CrtRenderer *crt_renderer_new(CrtScene *scene, const CrtMaterial *materials, size_t n_materials, const CrtLight *lights,
+                              size_t n_lights, const CrtCamera *camera, const CrtRenderSettings *settings,
+                              uint32_t tile_rank, uint32_t tile_world) {
+  CrtRenderer *R = nullptr;
+  (void)abi_guard("crt_renderer_new", [&] {  // nothing unwinds through the ABI: NULL + crt_last_error
+    R = renderer_new(scene, materials, n_materials, lights, n_lights, camera, settings, tile_rank, tile_world);
+    return (int)CRT_OK;
+  });
   return R;
 }
 void crt_renderer_free(CrtRenderer *r) { delete r; }
@@ -1725,7 +1739,7 @@ int crt_renderer_pixel_indices(const CrtRenderer *r, uint32_t *out) {
 }
 int crt_render_samples(CrtRenderer *r, uint32_t sample_begin, uint32_t sample_count, void *stream) {
   if (!r) return CRT_ERR_BAD_ARG;
-  return r->r.render(sample_begin, sample_count, (hipStream_t)stream, nullptr);
+  return abi_guard("crt_render_samples", [&] { return r->r.render(sample_begin, sample_count, (hipStream_t)stream, nullptr); });
 }
 int crt_render_samples_stats(CrtRenderer *r, uint32_t sample_begin, uint32_t sample_count, void *stream,
                              CrtTravStats host_stats[2]) {
@@ -1733,7 +1747,7 @@ int crt_render_samples_stats(CrtRenderer *r, uint32_t sample_begin, uint32_t sam
   CrtTravStats *d = nullptr;
   if (!CRT_HIP_OK(hipMalloc(&d, 2 * sizeof(CrtTravStats)))) return CRT_ERR_NO_DEVICE;
   (void)hipMemsetAsync(d, 0, 2 * sizeof(CrtTravStats), (hipStream_t)stream);
-  int rc = r->r.render(sample_begin, sample_count, (hipStream_t)stream, d);
+  int rc = abi_guard("crt_render_samples_stats", [&] { return r->r.render(sample_begin, sample_count, (hipStream_t)stream, d); });
   CrtTravStats h[2] = {};
   if (rc == CRT_OK && !CRT_HIP_OK(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream))) rc = CRT_ERR_NO_DEVICE;
   if (!CRT_HIP_OK(hipStreamSynchronize((hipStream_t)stream))) rc = CRT_ERR_NO_DEVICE;

@@ -40,7 +40,9 @@ typedef enum {
   CRT_ERR_BAD_ID = -2,     /* scene.rs:197-201 (panic in the reference) */
   CRT_ERR_NO_DEVICE = -3,  /* no gfx950 HIP device / HIP call failed */
   CRT_ERR_STACK = -4,      /* traversal stack capacity exceeded (never on trees the builder emits) */
-  CRT_ERR_UNSUPPORTED = -5 /* RoundCurves / CubicCurves (scene.rs:99-106): out of scope */
+  CRT_ERR_UNSUPPORTED = -5, /* RoundCurves / CubicCurves (scene.rs:99-106): out of scope */
+  CRT_ERR_NO_MEMORY = -6    /* a host allocation failed (the reference aborts); reason in crt_last_error. Nothing unwinds
+                             * through this ABI: a C or Rust host could not catch it */
 } CrtStatus;
 
 /* crust_rt::Ray (ray.rs:18-23): origin/dir are glam Vec3A (16-byte, w unused), then time, mask. 48 bytes. */

@@ -98,3 +98,25 @@ def test_shading_seam_argument_checks_need_no_device(crt):
         assert f(None, 3, 1, 5, 1, None) == -1                           # a table of 3 records without a pointer
     assert L.crt_gather_plan_assemble(None, None, None, None) == -1 and L.crt_gather_plan_padded_count(None) == 0
     assert L.crt_renderer_set_lanes(None, 2) == -1
+
+
+def test_nothing_unwinds_through_the_abi(crt):
+    """A host in C or Rust cannot catch a C++ exception: entry points that allocate host memory report
+    CRT_ERR_NO_MEMORY (reason in crt_last_error) instead — crt_reserve with a capacity no allocator can give
+    (Vec::reserve panics on it, scene.rs:174), and the builder is usable afterwards."""
+    import ctypes as C
+    L = crt.lib()
+    b = L.crt_builder_new()
+    try:
+        L.crt_reserve.argtypes = [C.c_void_p, C.c_size_t]
+        assert L.crt_reserve(b, C.c_size_t(2 ** 64 - 1)) == -6
+        assert b"crt_reserve" in L.crt_last_error()
+        assert L.crt_reserve(b, C.c_size_t(2 ** 62)) == -6  # under max_size, far beyond memory: bad_alloc
+        assert L.crt_reserve(b, 4) == 0
+        gid = C.c_uint32(99)
+        c = (C.c_float * 3)(0.0, 0.0, 0.0)
+        assert L.crt_attach_sphere(b, c, C.c_float(1.0), C.c_uint32(0xFFFFFFFF), C.byref(gid)) == 0 and gid.value == 0
+        assert L.crt_count(b) == 1
+    finally:
+        L.crt_builder_free(b)
+    assert crt._ERRORS[-6] == "CRT_ERR_NO_MEMORY"
