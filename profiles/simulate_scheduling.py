@@ -279,6 +279,10 @@ def main():
             ("D retire (emit+fetch), >=40", sim_affine(tr, rows=2, overhead=90, chain_min=24, fetch_min=40, emit_min=40, retire=True)),
             ("D retire (emit+fetch), >=24", sim_affine(tr, rows=2, overhead=90, chain_min=24, fetch_min=40, emit_min=24, retire=True)),
             ("D retire (emit+fetch), >=16", sim_affine(tr, rows=2, overhead=90, chain_min=24, fetch_min=40, emit_min=16, retire=True)),
+            # more rows per lane at the shipped form's realistic scheduling price (LDS for them exists only at fewer waves per
+            # SIMD: 3 rows x 3 waves = 9 rays per SIMD lane against the shipped 2 x 4 = 8)
+            ("D shipped form, 3 rows", sim_affine(tr, rows=3, overhead=90, chain_min=24, fetch_min=40, emit_min=40)),
+            ("D shipped form, 4 rows", sim_affine(tr, rows=4, overhead=90, chain_min=24, fetch_min=40, emit_min=40)),
         ):
             print(f"   {name:28s} wave-instr/ray {ins / len(tr):7.2f}   lane utilisation {use / (64.0 * ins):5.3f}")
 
